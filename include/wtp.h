@@ -1,0 +1,176 @@
+/*
+ * wtp.h — C ABI of libwtp, the MI355X (gfx950) neighbour/stencil engine behind
+ * WhatsThePoint.jl's `set_topology` / `repel` hot path.
+ *
+ * Every entry point below replaces the body of one reference function (citations are
+ * relative to the reference checkout, JuliaMeshless/WhatsThePoint.jl v0.3.1).  The
+ * reference has no FFI seam of its own: the seam is the set of Julia functions whose
+ * bodies a maintainer swaps for `ccall`s (INTEGRATION.md shows the Julia side).
+ *
+ * Conventions
+ *  - plain C, plain pointers and sizes; no exceptions or signals cross the ABI;
+ *  - every function returns a wtp_status (0 = OK); wtp_last_error(ctx) gives the text;
+ *  - host entry points (`xyz`, `idx_out`, ...) take HOST pointers, block until the
+ *    result is on the host; `_dev` entry points take DEVICE pointers on the context's
+ *    GPU and only enqueue + synchronise the context's stream;
+ *  - coordinates are AoS `n x dim` contiguous (the in-memory layout of Julia's
+ *    Vector{SVector{D,T}} / Vector{Point}, src/repel.jl:216), dim in {2,3};
+ *  - indices are int32, 0-based, in the caller's (snapshot-global) numbering:
+ *    boundary points first, then volume (src/cloud.jl:235-237);
+ *  - canonical neighbour order: ascending (d2, index) with
+ *    d2 = ((dx*dx + dy*dy) + dz*dz) evaluated in the cloud's float type, no FMA
+ *    contraction; distances returned are sqrt(d2) in that type;
+ *  - a context is not thread-safe (one caller at a time); several contexts may coexist.
+ */
+#ifndef WTP_H
+#define WTP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wtp_ctx wtp_ctx;
+
+typedef enum wtp_status {
+    WTP_OK = 0,
+    WTP_ERR_ARG = 1,      /* bad argument: the Julia shim maps it to ArgumentError (src/repel.jl:74) */
+    WTP_ERR_OOM = 2,      /* device or host allocation failed */
+    WTP_ERR_HIP = 3,      /* HIP runtime / kernel error */
+    WTP_ERR_STATE = 4,    /* call out of order (e.g. relax_step before relax_init) */
+    WTP_ERR_NO_DEVICE = 5 /* no usable gfx950 device: the library never falls back to a CPU path */
+} wtp_status;
+
+typedef enum wtp_dtype { WTP_F32 = 0, WTP_F64 = 1 } wtp_dtype;
+
+/* Force laws of src/repel_forces.jl:37,57-60,96-100,124-127 (u = r/s). */
+typedef enum wtp_force_kind {
+    WTP_FORCE_INVERSE_DISTANCE = 0,    /* 1/(u^2+beta)^2                       */
+    WTP_FORCE_SPACING_EQUILIBRIUM = 1, /* (1-u^2)/(u^2+beta)^2                 */
+    WTP_FORCE_CLIPPED_SPACING = 2,     /* max((u0^2-u^2)/(u^2+beta)^2, 0)  (default) */
+    WTP_FORCE_STRONG_SPACING = 3       /* (1-u^2)/(u^2+beta)^gamma             */
+} wtp_force_kind;
+
+typedef struct wtp_force_desc {
+    int32_t kind;  /* wtp_force_kind */
+    double beta;   /* softening, > 0 */
+    double u0;     /* support radius (clipped law only) */
+    double gamma;  /* core strength (strong law only) */
+} wtp_force_desc;
+
+/* Spacing callables of src/discretization/spacings.jl invoked inside the sweep
+ * (src/repel.jl:209,251,260). */
+typedef enum wtp_spacing_kind {
+    WTP_SPACING_CONSTANT = 0,  /* ConstantSpacing: spacings.jl:35-39 */
+    WTP_SPACING_PER_POINT = 1  /* host-evaluated s[n] in snapshot order; refresh with
+                                  wtp_relax_set_spacing (variable spacings; §8f item 3) */
+} wtp_spacing_kind;
+
+typedef struct wtp_spacing_desc {
+    int32_t kind;            /* wtp_spacing_kind */
+    double constant;         /* CONSTANT: the spacing (unitless, as ustrip gives it) */
+    const void* per_point;   /* PER_POINT: host array of n values of the cloud's dtype */
+} wtp_spacing_desc;
+
+/* Scalars the host-side stop logic of src/repel.jl:293-334 needs after one sweep. */
+typedef struct wtp_step_stats {
+    double max_force;  /* maximum(forces), forces[id] = |F|*s         (repel.jl:283,293) */
+    double sum_u;      /* sum_i nn_dist[i]/spacings[i+n_fixed]        (repel.jl:374-386) */
+    double sum_u2;     /* sum_i (nn_dist[i]/spacings[i+n_fixed])^2                        */
+    int64_t n_move;    /* number of movable points the sums run over                     */
+    int64_t argmin_i;  /* closest pair (repel.jl:396-403): snapshot-global index of the  */
+    int64_t argmin_j;  /*   movable point with the smallest nn_dist, and its neighbour;  */
+    double argmin_r;   /*   -1/-1/inf when n_move == 0                                    */
+    int64_t n_fallback;/* queries that left the 27-cell fast path (diagnostic)           */
+} wtp_step_stats;
+
+/* ---- lifetime ------------------------------------------------------------------ */
+
+/* Create a context on one GPU (n_dev must be 1: multi-GPU runs use one context per
+ * process/GPU, sharded by the host driver — SURVEY.md §8e). */
+int wtp_create(const int* device_ordinals, int n_dev, wtp_ctx** out);
+int wtp_destroy(wtp_ctx* ctx);
+/* UTF-8 text of the last non-zero status on this context ("" if none).  ctx may be
+ * NULL: then the text of the last failed wtp_create on this thread. */
+const char* wtp_last_error(const wtp_ctx* ctx);
+/* Library version string, for the binding's sanity check. */
+const char* wtp_version(void);
+
+/* ---- KNNTopology / KNearestSearch ------------------------------------------------ */
+
+/* Replaces _build_knn_neighbors (src/topology.jl:79-84) and the KNearestSearch +
+ * search/searchdists wrappers (src/neighbors.jl:1-21).
+ * include_self = 0: row i = the k nearest OTHER points (self removed by index), as
+ *                   set_topology stores them (k+1 query, first hit dropped);
+ * include_self = 1: row i = the k nearest points including i itself (raw `search`
+ *                   result: self first, test/neighbors.jl:54-56).
+ * idx_out: n*k int32 (row-major); dist_out: n*k values of dtype, or NULL.
+ * Errors: k < 1, or k > n - (include_self ? 0 : 1)  (the reference's kd-tree throws
+ * for k+1 > n), dim not in {2,3}, n < 1. */
+int wtp_knn(wtp_ctx* ctx, const void* xyz, int64_t n, int dim, int dtype, int k,
+            int include_self, int32_t* idx_out, void* dist_out);
+/* Same, device-resident input/output (bench and the sharded driver use this). */
+int wtp_knn_dev(wtp_ctx* ctx, const void* d_xyz, int64_t n, int dim, int dtype, int k,
+                int include_self, int32_t* d_idx_out, void* d_dist_out);
+
+/* ---- RadiusTopology / BallSearch --------------------------------------------------- */
+
+/* Replaces _build_radius_neighbors (src/topology.jl:91-97): all j != i with
+ * d2(i,j) <= r*r (inclusive).  Two-phase CSR so the caller allocates exactly:
+ * count fills counts_out[n]; the caller builds offsets[n+1] (exclusive scan, int64)
+ * and calls fill, which writes rows sorted by ascending (d2, index) into idx_out.
+ * fill refers to the cloud passed to the preceding count on the same context. */
+int wtp_radius_count(wtp_ctx* ctx, const void* xyz, int64_t n, int dim, int dtype,
+                     double r, int32_t* counts_out);
+int wtp_radius_fill(wtp_ctx* ctx, const int64_t* offsets, int32_t* idx_out);
+
+/* ---- repel: _relax! ------------------------------------------------------------------ */
+
+/* Replaces the setup of _relax! (src/repel.jl:207-241).  snap_xyz: the search snapshot,
+ * n points, the first n_fixed static (the boundary wall), the tail movable.
+ * k is the reference's `k` (self slot included: kk = min(k, n), repel.jl:208,259).
+ * alpha_lo/alpha_max: step bounds (repel.jl:85,226). */
+int wtp_relax_init(wtp_ctx* ctx, const void* snap_xyz, int64_t n, int64_t n_fixed, int dim,
+                   int dtype, const wtp_spacing_desc* spacing, const wtp_force_desc* force,
+                   int k, double alpha_lo, double alpha_max);
+
+/* One pass of src/repel.jl:244-293 plus the reductions of :293,374-403.
+ * rebuild != 0 refreshes the search snapshot from the current positions first
+ * (repel.jl:245-253); rebuild == 0 sweeps against the stale snapshot. */
+int wtp_relax_step(wtp_ctx* ctx, int rebuild, wtp_step_stats* stats);
+
+/* n_iters passes with no host round trip of coordinates; iteration i (0-based)
+ * rebuilds iff i % rebuild_every == 0.  conv_out[n_iters] receives max_force per
+ * iteration (may be NULL); last receives the final iteration's stats (may be NULL). */
+int wtp_relax_run(wtp_ctx* ctx, int n_iters, int rebuild_every, double* conv_out,
+                  wtp_step_stats* last);
+
+/* Current movable points, (n - n_fixed) x dim of dtype, snapshot order. */
+int wtp_relax_get(wtp_ctx* ctx, void* xyz_out);
+/* Per-point outputs of the last sweep, each n - n_fixed long (any may be NULL):
+ * forces (|F|*s), nn_dist (dtype), nn_id (int32 snapshot-global, -1 if none). */
+int wtp_relax_get_point_data(wtp_ctx* ctx, void* forces_out, void* nn_dist_out,
+                             int32_t* nn_id_out);
+/* Overwrite movable point i (0-based within the movable tail): _maybe_kick!'s write
+ * (src/repel.jl:431). */
+int wtp_relax_set(wtp_ctx* ctx, int64_t i, const void* xyz);
+/* p .= p_old (src/repel.jl:314): undo the last sweep. */
+int wtp_relax_revert(wtp_ctx* ctx);
+/* Refresh the PER_POINT spacing array (n values, snapshot order; repel.jl:251). */
+int wtp_relax_set_spacing(wtp_ctx* ctx, const void* spacing);
+/* Release the relax state (device buffers stay pooled in the context). */
+int wtp_relax_end(wtp_ctx* ctx);
+
+/* ---- measurement hooks (bench.py, profiles/) -------------------------------------- */
+
+/* Device time (ms, HIP events on the context's stream) spent in each phase since the
+ * last reset: [0] hash build, [1] neighbour sweep (dominant kernel), [2] fallback +
+ * reductions, [3] sweep-kernel launches counted.  */
+int wtp_timers_get(wtp_ctx* ctx, double out[4]);
+int wtp_timers_reset(wtp_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WTP_H */

@@ -1,0 +1,239 @@
+"""ctypes loader for the CPU oracle (oracle/wtp_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by bench.py's
+cpu_baseline leg — never by the product package (whatsthepoint.jl_amd/).  The oracle is a
+CPU restatement of the reference's neighbour/stencil path; see the header of
+wtp_oracle.c for what it follows (reference file:line) and what is pinned.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libwtp_oracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (oracle/Makefile).  Returns the .so path."""
+    src = [os.path.join(_HERE, f) for f in ("wtp_oracle.c", "wtp_oracle_impl.h", "Makefile")]
+    stale = force or not os.path.exists(_SO) or any(
+        os.path.getmtime(s) > os.path.getmtime(_SO) for s in src
+    )
+    if stale:
+        subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.wtpo_force_f32.restype = C.c_float
+        _lib.wtpo_force_f64.restype = C.c_double
+        _lib.wtpo_dnn_cv_f32.restype = C.c_float
+        _lib.wtpo_dnn_cv_f64.restype = C.c_double
+        _lib.wtpo_force_f32.argtypes = [C.c_int] + [C.c_float] * 4
+        _lib.wtpo_force_f64.argtypes = [C.c_int] + [C.c_double] * 4
+    return _lib
+
+
+def _suf(dtype) -> str:
+    dtype = np.dtype(dtype)
+    if dtype == np.float32:
+        return "f32"
+    if dtype == np.float64:
+        return "f64"
+    raise TypeError(f"oracle supports float32/float64, got {dtype}")
+
+
+def _ct(dtype):
+    return C.c_float if np.dtype(dtype) == np.float32 else C.c_double
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _xyz(xyz):
+    xyz = np.ascontiguousarray(xyz)
+    if xyz.ndim != 2 or xyz.shape[1] not in (2, 3):
+        raise ValueError("xyz must be (n, 2|3)")
+    return xyz
+
+
+def set_num_threads(n: int) -> None:
+    lib().wtpo_set_num_threads(C.c_int(n))
+
+
+def num_threads() -> int:
+    return int(lib().wtpo_num_threads())
+
+
+def gen_uniform(seed: int, n: int, dim: int = 3, dtype=np.float32, first: int = 0):
+    out = np.empty((n, dim), dtype=dtype)
+    getattr(lib(), f"wtpo_gen_uniform_{_suf(dtype)}")(
+        C.c_uint64(seed), C.c_int64(first), C.c_int64(n), C.c_int(dim), _p(out)
+    )
+    return out
+
+
+def knn(xyz, k: int, include_self: bool = False, method: str = "kdtree", want_dist: bool = True):
+    """Canonical k-NN lists (ascending (d2, index)).  method: 'brute' | 'kdtree'."""
+    xyz = _xyz(xyz)
+    n, dim = xyz.shape
+    idx = np.empty((n, k), dtype=np.int32)
+    dist = np.empty((n, k), dtype=xyz.dtype) if want_dist else None
+    fn = getattr(lib(), f"wtpo_knn_{method}_{_suf(xyz.dtype)}")
+    rc = fn(_p(xyz), C.c_int64(n), C.c_int(dim), C.c_int(k), C.c_int(int(include_self)), _p(idx), _p(dist))
+    if rc != 0:
+        raise ValueError("oracle knn: bad argument (k too large for n?)")
+    return (idx, dist) if want_dist else idx
+
+
+def radius(xyz, r: float, method: str = "kdtree"):
+    """CSR radius stencils: (offsets int64[n+1], idx int32[nnz]), rows sorted by (d2, index)."""
+    xyz = _xyz(xyz)
+    n, dim = xyz.shape
+    suf = _suf(xyz.dtype)
+    counts = np.empty(n, dtype=np.int32)
+    rr = _ct(xyz.dtype)(r)
+    if method == "brute":
+        rc = getattr(lib(), f"wtpo_radius_count_brute_{suf}")(_p(xyz), C.c_int64(n), C.c_int(dim), rr, _p(counts))
+    else:
+        rc = getattr(lib(), f"wtpo_radius_kdtree_{suf}")(_p(xyz), C.c_int64(n), C.c_int(dim), rr, _p(counts), None, None)
+    if rc != 0:
+        raise ValueError("oracle radius: bad argument")
+    offsets = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(counts, out=offsets[1:])
+    idx = np.empty(int(offsets[-1]), dtype=np.int32)
+    if method == "brute":
+        getattr(lib(), f"wtpo_radius_fill_brute_{suf}")(_p(xyz), C.c_int64(n), C.c_int(dim), rr, _p(offsets), _p(idx))
+    else:
+        getattr(lib(), f"wtpo_radius_kdtree_{suf}")(_p(xyz), C.c_int64(n), C.c_int(dim), rr, _p(counts), _p(offsets), _p(idx))
+    return offsets, idx
+
+
+def force(kind: int, beta, u0, gamma, u, dtype=np.float64):
+    fn = getattr(lib(), f"wtpo_force_{_suf(dtype)}")
+    return float(fn(int(kind), float(beta), float(u0), float(gamma), float(u)))
+
+
+def _spacings(spacing, n, dtype):
+    if np.isscalar(spacing):
+        return np.full(n, spacing, dtype=dtype)
+    s = np.ascontiguousarray(spacing, dtype=dtype)
+    if s.shape != (n,):
+        raise ValueError("spacing array must have n entries (snapshot order)")
+    return s
+
+
+def relax_sweep(snap, n_fixed: int, spacing, force_kind=2, beta=0.2, u0=1.0, gamma=3.0, k=21,
+                alpha_lo=None, alpha_max=None, p_old=None):
+    """One sweep of _relax! (src/repel.jl:256-292).  Returns dict(p, forces, nn_dist, nn_id)."""
+    snap = _xyz(snap)
+    n, dim = snap.shape
+    dt = snap.dtype
+    n_move = n - n_fixed
+    sp = _spacings(spacing, n, dt)
+    p_old = np.ascontiguousarray(snap[n_fixed:] if p_old is None else p_old, dtype=dt)
+    p = np.empty((n_move, dim), dtype=dt)
+    forces = np.empty(n_move, dtype=dt)
+    nn_dist = np.empty(n_move, dtype=dt)
+    nn_id = np.empty(n_move, dtype=np.int32)
+    ct = _ct(dt)
+    rc = getattr(lib(), f"wtpo_relax_sweep_{_suf(dt)}")(
+        _p(snap), C.c_int64(n), C.c_int64(n_fixed), C.c_int(dim), _p(p_old), _p(sp),
+        C.c_int(force_kind), ct(beta), ct(u0), ct(gamma), C.c_int(k), ct(alpha_lo), ct(alpha_max),
+        _p(p), _p(forces), _p(nn_dist), _p(nn_id),
+    )
+    if rc != 0:
+        raise ValueError("oracle relax_sweep: bad argument")
+    return dict(p=p, forces=forces, nn_dist=nn_dist, nn_id=nn_id)
+
+
+def relax_loop(snap, n_fixed: int, spacing, force_kind=2, beta=0.2, u0=1.0, gamma=3.0, k=21,
+               alpha_lo=None, alpha_max=None, max_iters=1000, tol=1e-6, rebuild_every=1,
+               stall_after=50, cv_target=0.0):
+    """The whole _relax! loop (src/repel.jl:243-334).  Returns dict(p, conv, stop_reason)."""
+    snap = np.array(_xyz(snap), copy=True)
+    n, dim = snap.shape
+    dt = snap.dtype
+    sp = _spacings(spacing, n, dt)
+    p = np.array(snap[n_fixed:], copy=True)
+    conv = np.zeros(max(max_iters, 1), dtype=dt)
+    reason = C.c_int(0)
+    ct = _ct(dt)
+    nconv = getattr(lib(), f"wtpo_relax_loop_{_suf(dt)}")(
+        _p(snap), C.c_int64(n), C.c_int64(n_fixed), C.c_int(dim), _p(p), _p(sp), C.c_int(force_kind),
+        ct(beta), ct(u0), ct(gamma), C.c_int(k), ct(alpha_lo), ct(alpha_max), C.c_int(max_iters),
+        C.c_double(tol), C.c_int(rebuild_every), C.c_int(stall_after), C.c_double(cv_target),
+        _p(conv), C.byref(reason),
+    )
+    if nconv < 0:
+        raise ValueError("rebuild_every must be >= 1")
+    return dict(p=p, conv=conv[:nconv].copy(), stop_reason=int(reason.value))
+
+
+def dnn_cv(nn_dist, spacings, n_fixed: int):
+    nn_dist = np.ascontiguousarray(nn_dist)
+    dt = nn_dist.dtype
+    sp = np.ascontiguousarray(spacings, dtype=dt)
+    s1, s2 = C.c_double(0), C.c_double(0)
+    cv = getattr(lib(), f"wtpo_dnn_cv_{_suf(dt)}")(
+        _p(nn_dist), _p(sp), C.c_int64(len(nn_dist)), C.c_int64(n_fixed), C.byref(s1), C.byref(s2)
+    )
+    return float(cv), float(s1.value), float(s2.value)
+
+
+def closest_pair(nn_dist, nn_id, spacings, n_fixed: int):
+    nn_dist = np.ascontiguousarray(nn_dist)
+    dt = nn_dist.dtype
+    sp = np.ascontiguousarray(spacings, dtype=dt)
+    nn_id = np.ascontiguousarray(nn_id, dtype=np.int32)
+    ct = _ct(dt)
+    r, s = ct(0), ct(0)
+    a, b = C.c_int64(0), C.c_int64(0)
+    getattr(lib(), f"wtpo_closest_pair_{_suf(dt)}")(
+        _p(nn_dist), _p(nn_id), _p(sp), C.c_int64(len(nn_dist)), C.c_int64(n_fixed),
+        C.byref(r), C.byref(s), C.byref(a), C.byref(b),
+    )
+    return dict(r=float(r.value), s=float(s.value), idx_a=int(a.value), idx_b=int(b.value))
+
+
+def cull_mask(xyz, spacings, ratio: float):
+    xyz = _xyz(xyz)
+    n, dim = xyz.shape
+    sp = np.ascontiguousarray(spacings, dtype=xyz.dtype)
+    keep = np.empty(n, dtype=np.uint8)
+    getattr(lib(), f"wtpo_cull_mask_{_suf(xyz.dtype)}")(
+        _p(xyz), C.c_int64(n), C.c_int(dim), _p(sp), _ct(xyz.dtype)(ratio), _p(keep)
+    )
+    return keep.astype(bool)
+
+
+def spacing_loglike(xyz, bnd, base_size, growth_rate):
+    xyz, bnd = _xyz(xyz), _xyz(bnd).astype(np.asarray(xyz).dtype)
+    out = np.empty(len(xyz), dtype=xyz.dtype)
+    ct = _ct(xyz.dtype)
+    getattr(lib(), f"wtpo_spacing_loglike_{_suf(xyz.dtype)}")(
+        _p(xyz), C.c_int64(len(xyz)), C.c_int(xyz.shape[1]), _p(bnd), C.c_int64(len(bnd)),
+        ct(base_size), ct(growth_rate), _p(out),
+    )
+    return out
+
+
+def spacing_boundary_layer(xyz, bnd, at_wall, bulk, layer_thickness):
+    xyz, bnd = _xyz(xyz), _xyz(bnd).astype(np.asarray(xyz).dtype)
+    out = np.empty(len(xyz), dtype=xyz.dtype)
+    ct = _ct(xyz.dtype)
+    getattr(lib(), f"wtpo_spacing_boundary_layer_{_suf(xyz.dtype)}")(
+        _p(xyz), C.c_int64(len(xyz)), C.c_int(xyz.shape[1]), _p(bnd), C.c_int64(len(bnd)),
+        ct(at_wall), ct(bulk), ct(layer_thickness), _p(out),
+    )
+    return out

@@ -1,0 +1,103 @@
+/*
+ * wtp_oracle.c — CPU oracle for the neighbour/stencil hot path of WhatsThePoint.jl.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (whatsthepoint.jl_amd/) imports,
+ * links or calls this file; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg do, and there only as the checker / reported baseline.
+ *
+ * What it restates (reference paths relative to the reference checkout):
+ *   src/topology.jl:79-100   k+1 query / drop self; radius inclusive / drop self by index
+ *   src/repel.jl:202-339     _relax! loop, :350-403 helpers, :565-580 cull mask
+ *   src/repel_forces.jl:37,57-60,96-100,124-127   the four force laws
+ *   src/discretization/spacings.jl:19-23,67-72,121-133   variable spacings
+ * Third-party arithmetic it stands in for (source NOT in the reference tree, versions only
+ * compat-bounded in Project.toml:39-45): NearestNeighbors.jl 0.4.8+ (KDTree, knn, knn!,
+ * inrange), Meshes.jl 0.56/0.57 (KNearestSearch, BallSearch), Distances.jl 0.10
+ * (Euclidean).  Published algorithm restated: exact kd-tree search, squared distance
+ * accumulated in coordinate order, sqrt applied to the final values.
+ *
+ * PARITY STATUS.  The reference cannot run here (no Julia toolchain in the image; nothing
+ * was refused).  Pinned against the reference's own tests: the closed-form known answers
+ * of test/neighbors.jl:34-57, test/topology.jl:43-66, test/metrics.jl:115-143,
+ * test/repel.jl:117-183 (force laws), :301-325 (cull masks) — see tests/test_oracle_kat.py.
+ * NOT pinned by anything the reference holds: the order of equidistant neighbours, which
+ * equidistant point takes slot k, and repelled coordinates ("parity unpinned" for those;
+ * SURVEY.md §8c).  The canonical rule defined here is ascending (d2, index).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+#define REAL float
+#define SUF f32
+#define SQRT sqrtf
+#define POW powf
+#define EXP expf
+#define REAL_MAX FLT_MAX
+#include "wtp_oracle_impl.h"
+#undef REAL
+#undef SUF
+#undef SQRT
+#undef POW
+#undef EXP
+#undef REAL_MAX
+
+#define REAL double
+#define SUF f64
+#define SQRT sqrt
+#define POW pow
+#define EXP exp
+#define REAL_MAX DBL_MAX
+#include "wtp_oracle_impl.h"
+#undef REAL
+#undef SUF
+#undef SQRT
+#undef POW
+#undef EXP
+#undef REAL_MAX
+
+/* Counter-based synthetic input generator: splitmix64 of
+ * seed*2^40 + 3*i + axis, top 24 bits * 2^-24 -> [0,1).  Implemented identically in
+ * whatsthepoint.jl_amd/synth.py (numpy) and csrc/wtp_synth.hip (device). */
+static inline uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+void wtpo_gen_uniform_f32(uint64_t seed, int64_t first, int64_t n, int dim, float* out) {
+    for (int64_t i = 0; i < n; ++i)
+        for (int a = 0; a < dim; ++a) {
+            uint64_t h = splitmix64((seed << 40) + 3ull * (uint64_t)(first + i) + (uint64_t)a);
+            out[i * dim + a] = (float)(h >> 40) * (1.0f / 16777216.0f);
+        }
+}
+
+void wtpo_gen_uniform_f64(uint64_t seed, int64_t first, int64_t n, int dim, double* out) {
+    for (int64_t i = 0; i < n; ++i)
+        for (int a = 0; a < dim; ++a) {
+            uint64_t h = splitmix64((seed << 40) + 3ull * (uint64_t)(first + i) + (uint64_t)a);
+            out[i * dim + a] = (double)(float)(h >> 40) * (1.0 / 16777216.0);
+        }
+}
+
+int wtpo_num_threads(void) {
+#ifdef _OPENMP
+    extern int omp_get_max_threads(void);
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+void wtpo_set_num_threads(int n) {
+#ifdef _OPENMP
+    extern void omp_set_num_threads(int);
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
