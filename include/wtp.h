@@ -170,6 +170,12 @@ int wtp_relax_end(wtp_ctx* ctx);
 int wtp_timers_get(wtp_ctx* ctx, double out[4]);
 int wtp_timers_reset(wtp_ctx* ctx);
 
+/* Synthetic workload generator of SURVEY.md §8d, written straight into device memory:
+ * value(i, axis) = (splitmix64(seed*2^40 + 3*(first+i) + axis) >> 40) * 2^-24.
+ * d_out: n x dim of dtype on the context's GPU.  (bench.py / sharded driver only.) */
+int wtp_gen_uniform_dev(wtp_ctx* ctx, uint64_t seed, int64_t first, int64_t n, int dim, int dtype,
+                        void* d_out);
+
 #ifdef __cplusplus
 }
 #endif

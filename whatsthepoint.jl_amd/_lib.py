@@ -1,0 +1,108 @@
+"""ctypes binding of libwtp.so (include/wtp.h).  Loading fails loudly: there is no CPU path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "libwtp.so")
+
+WTP_OK, WTP_ERR_ARG, WTP_ERR_OOM, WTP_ERR_HIP, WTP_ERR_STATE, WTP_ERR_NO_DEVICE = range(6)
+WTP_F32, WTP_F64 = 0, 1
+
+
+class WtpError(RuntimeError):
+    """Non-argument failure reported by libwtp (the Julia shim raises ErrorException)."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"libwtp status {code}: {msg}")
+        self.code = code
+
+
+class WtpArgumentError(ValueError):
+    """WTP_ERR_ARG: the reference throws ArgumentError for the same input (src/repel.jl:74)."""
+
+
+class ForceDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("beta", C.c_double), ("u0", C.c_double), ("gamma", C.c_double)]
+
+
+class SpacingDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("constant", C.c_double), ("per_point", C.c_void_p)]
+
+
+class StepStats(C.Structure):
+    _fields_ = [
+        ("max_force", C.c_double), ("sum_u", C.c_double), ("sum_u2", C.c_double),
+        ("n_move", C.c_int64), ("argmin_i", C.c_int64), ("argmin_j", C.c_int64),
+        ("argmin_r", C.c_double), ("n_fallback", C.c_int64),
+    ]
+
+
+# every symbol include/wtp.h declares: name -> (restype, argtypes)
+_vp, _i, _i64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_double
+SIGNATURES = {
+    "wtp_create": (_i, [C.POINTER(_i), _i, C.POINTER(_vp)]),
+    "wtp_destroy": (_i, [_vp]),
+    "wtp_last_error": (C.c_char_p, [_vp]),
+    "wtp_version": (C.c_char_p, []),
+    "wtp_knn": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp]),
+    "wtp_knn_dev": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp]),
+    "wtp_radius_count": (_i, [_vp, _vp, _i64, _i, _i, _d, _vp]),
+    "wtp_radius_fill": (_i, [_vp, _vp, _vp]),
+    "wtp_relax_init": (_i, [_vp, _vp, _i64, _i64, _i, _i, C.POINTER(SpacingDesc), C.POINTER(ForceDesc), _i, _d, _d]),
+    "wtp_relax_step": (_i, [_vp, _i, C.POINTER(StepStats)]),
+    "wtp_relax_run": (_i, [_vp, _i, _i, _vp, C.POINTER(StepStats)]),
+    "wtp_relax_get": (_i, [_vp, _vp]),
+    "wtp_relax_get_point_data": (_i, [_vp, _vp, _vp, _vp]),
+    "wtp_relax_set": (_i, [_vp, _i64, _vp]),
+    "wtp_relax_revert": (_i, [_vp]),
+    "wtp_relax_set_spacing": (_i, [_vp, _vp]),
+    "wtp_relax_end": (_i, [_vp]),
+    "wtp_timers_get": (_i, [_vp, C.POINTER(_d)]),
+    "wtp_timers_reset": (_i, [_vp]),
+    "wtp_gen_uniform_dev": (_i, [_vp, C.c_uint64, _i64, _i64, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libwtp.so for gfx950 with hipcc (csrc/Makefile).  Works without a GPU."""
+    res = subprocess.run(["make", "-C", CSRC, "-j4"], capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("building libwtp.so failed:\n" + res.stdout[-4000:] + res.stderr[-4000:])
+    if verbose:
+        print(res.stdout[-2000:])
+    return SO_PATH
+
+
+def load():
+    """dlopen libwtp.so and bind every symbol of include/wtp.h (no compute is called)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError(
+            f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
+        )
+    lib = C.CDLL(SO_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(ctx_handle, rc: int):
+    if rc == WTP_OK:
+        return
+    msg = load().wtp_last_error(ctx_handle)
+    msg = msg.decode("utf-8", "replace") if msg else ""
+    if rc == WTP_ERR_ARG:
+        raise WtpArgumentError(msg)
+    raise WtpError(rc, msg)

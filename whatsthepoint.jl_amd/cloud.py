@@ -1,0 +1,169 @@
+"""Point containers — only what the hot path touches (src/surface.jl:167-205,
+src/boundary.jl:164, src/volume.jl:97-125, src/cloud.jl:178-237): coordinates as numpy
+arrays, `points()` = boundary first then volume (the global index space), and the functional
+`set_topology` / in-place `rebuild_topology` verbs.  Normals, areas, units, I/O stay in Julia."""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+
+from . import topology as T
+from .engine import default_context
+
+
+def _as_points(p, dtype=None):
+    p = np.asarray(p)
+    if p.ndim != 2 or p.shape[1] not in (2, 3):
+        raise ValueError("points must have shape (n, 2) or (n, 3)")
+    if dtype is not None:
+        p = p.astype(dtype, copy=False)
+    elif p.dtype not in (np.float32, np.float64):
+        p = p.astype(np.float64)
+    return np.ascontiguousarray(p)
+
+
+class _HasTopology:
+    topology: T.AbstractTopology
+
+    def hastopology(self) -> bool:
+        return not isinstance(self.topology, T.NoTopology)
+
+    def neighbors(self, i=None):
+        return T.neighbors(self.topology, i)
+
+    def _with(self, topo):
+        raise NotImplementedError
+
+    def set_topology(self, kind, param, ctx=None):
+        """Functional: returns a NEW container carrying the built topology
+        (src/cloud.jl:200-217, src/surface.jl:167-194, src/volume.jl:97-114)."""
+        ctx = ctx or default_context()
+        pts = self.points()
+        if kind is T.KNNTopology:
+            return self._with(T.KNNTopology(T.build_knn_neighbors(ctx, pts, int(param)), int(param)))
+        if kind is T.RadiusTopology:
+            return self._with(T.RadiusTopology(T.build_radius_neighbors(ctx, pts, param), param))
+        raise TypeError("set_topology expects KNNTopology or RadiusTopology")
+
+    def rebuild_topology(self, ctx=None):
+        """In place, same parameters; no-op for NoTopology (src/cloud.jl:224-228)."""
+        T.rebuild_topology(ctx or default_context(), self.topology, self.points())
+        return None
+
+
+class PointSurface(_HasTopology):
+    def __init__(self, points, topology=None):
+        self._points = _as_points(points)
+        self.topology = topology or T.NoTopology()
+
+    def points(self):
+        return self._points
+
+    def __len__(self):
+        return len(self._points)
+
+    def _with(self, topo):
+        return PointSurface(self._points, topo)
+
+
+class PointVolume(_HasTopology):
+    def __init__(self, points=None, dim: int = 3, dtype=np.float64, topology=None):
+        self._points = _as_points(points) if points is not None else np.zeros((0, dim), dtype=dtype)
+        self.topology = topology or T.NoTopology()
+
+    def points(self):
+        return self._points
+
+    def __len__(self):
+        return len(self._points)
+
+    def _with(self, topo):
+        return PointVolume(self._points, topology=topo)
+
+
+class PointBoundary:
+    """Named surfaces; points(boundary) concatenates them in insertion order (src/boundary.jl:164)."""
+
+    def __init__(self, points=None, name: str = "surface1", surfaces=None):
+        self.surfaces = OrderedDict()
+        if surfaces is not None:
+            for k, v in surfaces.items():
+                self.surfaces[k] = v if isinstance(v, PointSurface) else PointSurface(v)
+        elif points is not None:
+            self.surfaces[name] = points if isinstance(points, PointSurface) else PointSurface(points)
+
+    def points(self):
+        parts = [s.points() for s in self.surfaces.values()]
+        return np.concatenate(parts, axis=0) if parts else np.zeros((0, 3))
+
+    def __len__(self):
+        return sum(len(s) for s in self.surfaces.values())
+
+    def __getitem__(self, name):
+        return self.surfaces[name]
+
+
+class PointCloud(_HasTopology):
+    def __init__(self, boundary, volume=None, topology=None):
+        self.boundary = boundary if isinstance(boundary, PointBoundary) else PointBoundary(boundary)
+        bp = self.boundary.points()
+        self.volume = volume if isinstance(volume, PointVolume) else PointVolume(
+            volume, dim=bp.shape[1], dtype=bp.dtype)
+        self.topology = topology or T.NoTopology()
+
+    def points(self):
+        """vcat(points(boundary), points(volume)): fresh array, boundary first (src/cloud.jl:235-237)."""
+        bp, vp = self.boundary.points(), self.volume.points()
+        if len(vp) == 0:
+            return np.array(bp, copy=True)
+        dt = np.promote_types(bp.dtype, vp.dtype)
+        return np.concatenate([bp.astype(dt, copy=False), vp.astype(dt, copy=False)], axis=0)
+
+    def __len__(self):
+        return len(self.boundary) + len(self.volume)
+
+    def _with(self, topo):
+        return PointCloud(self.boundary, self.volume, topo)
+
+    def __setitem__(self, name, surf):
+        """cloud[:name] = surf rebuilds the topology implicitly (src/cloud.jl:86-90)."""
+        self.boundary.surfaces[name] = surf if isinstance(surf, PointSurface) else PointSurface(surf)
+        self.rebuild_topology()
+
+
+# free-function spellings of the reference verbs
+def points(x):
+    return x.points()
+
+
+def set_topology(x, kind, param, ctx=None):
+    return x.set_topology(kind, param, ctx=ctx)
+
+
+def rebuild_topology(x, ctx=None):
+    return x.rebuild_topology(ctx=ctx)
+
+
+def hastopology(x) -> bool:
+    return x.hastopology()
+
+
+def neighbors(x, i=None):
+    return x.neighbors(i) if isinstance(x, _HasTopology) else T.neighbors(x, i)
+
+
+# KNearestSearch / search / searchdists wrappers (src/neighbors.jl:1-21)
+class KNearestSearch:
+    def __init__(self, cloud, k: int):
+        self.points = cloud.points() if hasattr(cloud, "points") else _as_points(cloud)
+        self.k = int(k)
+
+
+def search(cloud, method: KNearestSearch, ctx=None):
+    """Per point the k nearest INCLUDING itself, ascending (self first: test/neighbors.jl:54-56)."""
+    return (ctx or default_context()).knn(method.points, method.k, include_self=True)
+
+
+def searchdists(cloud, method: KNearestSearch, ctx=None):
+    return (ctx or default_context()).knn(method.points, method.k, include_self=True, return_dist=True)

@@ -1,0 +1,683 @@
+// wtp_api.hip — the C ABI of include/wtp.h: context, buffer pool, host<->device staging and
+// the call sequences that replace _build_knn_neighbors / _build_radius_neighbors
+// (src/topology.jl:79-97) and the body of _relax!'s loop (src/repel.jl:243-334).
+// No CPU fallback exists: without a usable gfx950 device wtp_create fails.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "wtp_internal.hpp"
+
+namespace wtp {
+
+static thread_local std::string g_create_err;
+
+int fail(wtp_ctx* ctx, int code, const std::string& msg) {
+    if (ctx)
+        ctx->err = msg;
+    else
+        g_create_err = msg;
+    return code;
+}
+
+int ensure(wtp_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return WTP_OK;
+    if (b.p) {
+        hipFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 16 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        (void)hipGetLastError(); // clear sticky OOM
+        e = hipMalloc(&b.p, bytes);
+        want = bytes;
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        b.p = nullptr;
+        return fail(ctx, WTP_ERR_OOM, "hipMalloc of " + std::to_string(bytes) + " bytes failed");
+    }
+    b.cap = want;
+    return WTP_OK;
+}
+
+static int ensure_pinned(wtp_ctx* ctx, size_t bytes) {
+    if (ctx->host_pinned_cap >= bytes) return WTP_OK;
+    if (ctx->host_pinned) hipHostFree(ctx->host_pinned);
+    ctx->host_pinned = nullptr;
+    ctx->host_pinned_cap = 0;
+    WTP_HIP(ctx, hipHostMalloc(&ctx->host_pinned, bytes, hipHostMallocDefault));
+    ctx->host_pinned_cap = bytes;
+    return WTP_OK;
+}
+
+// ---- timing spans -----------------------------------------------------------------------------
+static int take_event(wtp_ctx* ctx) {
+    if (ctx->ev_used == (int)ctx->ev_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return -1;
+        ctx->ev_pool.push_back(e);
+    }
+    return ctx->ev_used++;
+}
+
+int span_begin(wtp_ctx* ctx, int kind) {
+    if (!ctx->timing) return -1;
+    if (ctx->spans.size() > 8192) spans_collect(ctx); // bounded pool; costs one sync
+    int a = take_event(ctx), b = take_event(ctx);
+    if (a < 0 || b < 0) return -1;
+    hipEventRecord(ctx->ev_pool[a], ctx->stream);
+    ctx->spans.push_back({a, b, kind});
+    return (int)ctx->spans.size() - 1;
+}
+
+void span_end(wtp_ctx* ctx, int span) {
+    if (span < 0) return;
+    hipEventRecord(ctx->ev_pool[ctx->spans[span].b], ctx->stream);
+}
+
+void spans_collect(wtp_ctx* ctx) {
+    if (ctx->spans.empty()) return;
+    hipStreamSynchronize(ctx->stream);
+    for (auto& s : ctx->spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->ev_pool[s.a], ctx->ev_pool[s.b]) == hipSuccess) {
+            if (s.kind == 0) ctx->t_hash += ms;
+            else if (s.kind == 1) ctx->t_sweep += ms;
+            else ctx->t_other += ms;
+        }
+    }
+    ctx->spans.clear();
+    ctx->ev_used = 0;
+}
+
+static int sync(wtp_ctx* ctx) {
+    WTP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return WTP_OK;
+}
+
+static size_t tsize(int dtype) { return dtype == WTP_F64 ? 8 : 4; }
+
+static int check_cloud(wtp_ctx* ctx, const void* xyz, int64_t n, int dim, int dtype) {
+    if (!ctx) return WTP_ERR_ARG;
+    if (!xyz) return fail(ctx, WTP_ERR_ARG, "xyz is NULL");
+    if (n < 1) return fail(ctx, WTP_ERR_ARG, "n must be >= 1");
+    if (n > 2000000000LL) return fail(ctx, WTP_ERR_ARG, "n exceeds the int32 index space");
+    if (dim != 2 && dim != 3) return fail(ctx, WTP_ERR_ARG, "dim must be 2 or 3");
+    if (dtype != WTP_F32 && dtype != WTP_F64) return fail(ctx, WTP_ERR_ARG, "dtype must be WTP_F32 or WTP_F64");
+    return WTP_OK;
+}
+
+// ---- topology -----------------------------------------------------------------------------------
+template <typename T>
+static int knn_dev_t(wtp_ctx* ctx, const T* d_xyz, int64_t n, int dim, int k, int include_self,
+                     int32_t* d_idx, T* d_dist) {
+    int rc;
+    if ((rc = ensure(ctx, ctx->pts[0], sizeof(Pt<T>) * (size_t)n))) return rc;
+    if ((rc = ensure(ctx, ctx->pts[1], sizeof(Pt<T>) * (size_t)n))) return rc;
+    if ((rc = ensure(ctx, ctx->fb_list, sizeof(int32_t) * (size_t)n))) return rc;
+    if ((rc = ensure(ctx, ctx->fb_count, 64))) return rc;
+    Pt<T>* raw = (Pt<T>*)ctx->pts[0].p;
+    Pt<T>* sorted = (Pt<T>*)ctx->pts[1].p;
+    int sp = span_begin(ctx, 0);
+    if ((rc = load_points<T>(ctx, d_xyz, raw, n, dim))) return rc;
+    // neighbours sought per query inside the structure: k others + self
+    if ((rc = build_hash<T>(ctx, raw, sorted, n, dim, include_self ? k : k + 1, 0.0))) return rc;
+    span_end(ctx, sp);
+    SearchArgs<T> a{};
+    a.grid = (const Grid<T>*)ctx->grid.p;
+    a.snap = sorted;
+    a.query = sorted;
+    a.cell_start = (const int32_t*)ctx->cell_start.p;
+    a.n = (int32_t)n;
+    a.k = k;
+    a.include_self = include_self;
+    a.idx_out = d_idx;
+    a.dist_out = d_dist;
+    a.fb_list = (int32_t*)ctx->fb_list.p;
+    a.fb_count = (int32_t*)ctx->fb_count.p;
+    sp = span_begin(ctx, 1);
+    rc = launch_topology<T>(ctx, a);
+    span_end(ctx, sp);
+    ctx->n_sweep_launches += 1;
+    ctx->relax.have_tree = false; // pts[] reused
+    ctx->rad_valid = false;
+    return rc;
+}
+
+static int check_idle(wtp_ctx* ctx) {
+    if (ctx->relax.active)
+        return fail(ctx, WTP_ERR_STATE,
+                    "context holds a relax session (its buffers are live): call wtp_relax_end or use another context");
+    return WTP_OK;
+}
+
+static int check_k(wtp_ctx* ctx, int64_t n, int k, int include_self) {
+    if (k < 1) return fail(ctx, WTP_ERR_ARG, "k must be >= 1");
+    if ((int64_t)k > n - (include_self ? 0 : 1))
+        return fail(ctx, WTP_ERR_ARG, "k exceeds the number of available neighbours (k+1 > n)");
+    if (k > kGenericKMax) return fail(ctx, WTP_ERR_ARG, "k > 128 is not supported");
+    return WTP_OK;
+}
+
+} // namespace wtp
+
+using namespace wtp;
+
+#define WTP_API extern "C"
+
+WTP_API const char* wtp_version(void) { return "wtp-mi355x 0.1.0 (gfx950)"; }
+
+WTP_API const char* wtp_last_error(const wtp_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+WTP_API int wtp_create(const int* device_ordinals, int n_dev, wtp_ctx** out) {
+    if (!out) return fail(nullptr, WTP_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (n_dev != 1)
+        return fail(nullptr, WTP_ERR_ARG, "one context drives one GPU: create one context per process/GPU");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 1) {
+        (void)hipGetLastError();
+        return fail(nullptr, WTP_ERR_NO_DEVICE, "no HIP device visible (libwtp has no CPU path)");
+    }
+    int dev = device_ordinals ? device_ordinals[0] : 0;
+    if (dev < 0 || dev >= count) return fail(nullptr, WTP_ERR_ARG, "device ordinal out of range");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess)
+        return fail(nullptr, WTP_ERR_HIP, "hipGetDeviceProperties failed");
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(nullptr, WTP_ERR_NO_DEVICE,
+                    std::string("device is ") + prop.gcnArchName + ", libwtp is built for gfx950 only");
+    if (hipSetDevice(dev) != hipSuccess) return fail(nullptr, WTP_ERR_HIP, "hipSetDevice failed");
+    wtp_ctx* ctx = new wtp_ctx();
+    ctx->device = dev;
+    ctx->sm_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, WTP_ERR_HIP, "hipStreamCreate failed");
+    }
+    if (const char* e = getenv("WTP_RHO")) ctx->rho = atof(e) > 0 ? atof(e) : ctx->rho;
+    if (const char* e = getenv("WTP_GAMMA_CAP")) ctx->gamma_cap = atof(e) > 0 ? atof(e) : ctx->gamma_cap;
+    if (const char* e = getenv("WTP_FORCE_GENERIC")) ctx->force_generic = atoi(e);
+    if (const char* e = getenv("WTP_TIMING")) ctx->timing = atoi(e) != 0;
+    *out = ctx;
+    return WTP_OK;
+}
+
+WTP_API int wtp_destroy(wtp_ctx* ctx) {
+    if (!ctx) return WTP_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    DevBuf* bufs[] = {&ctx->pts[0], &ctx->pts[1], &ctx->pts[2], &ctx->raw_in, &ctx->cell_of, &ctx->rank_of,
+                      &ctx->cell_cnt, &ctx->cell_start, &ctx->scan_tmp, &ctx->grid, &ctx->bbox_part,
+                      &ctx->idx_out, &ctx->dist_out, &ctx->counts_out, &ctx->forces, &ctx->nn_dist,
+                      &ctx->nn_id, &ctx->spacing_pp, &ctx->partials, &ctx->stats, &ctx->fb_list,
+                      &ctx->fb_count, &ctx->scratch};
+    for (DevBuf* b : bufs)
+        if (b->p) hipFree(b->p);
+    if (ctx->host_pinned) hipHostFree(ctx->host_pinned);
+    for (auto e : ctx->ev_pool) hipEventDestroy(e);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return WTP_OK;
+}
+
+WTP_API int wtp_knn_dev(wtp_ctx* ctx, const void* d_xyz, int64_t n, int dim, int dtype, int k, int include_self,
+                int32_t* d_idx_out, void* d_dist_out) {
+    int rc = check_cloud(ctx, d_xyz, n, dim, dtype);
+    if (rc) return rc;
+    if ((rc = check_k(ctx, n, k, include_self))) return rc;
+    if ((rc = check_idle(ctx))) return rc;
+    if (!d_idx_out) return fail(ctx, WTP_ERR_ARG, "idx_out is NULL");
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    if (dtype == WTP_F32)
+        rc = knn_dev_t<float>(ctx, (const float*)d_xyz, n, dim, k, include_self, d_idx_out, (float*)d_dist_out);
+    else
+        rc = knn_dev_t<double>(ctx, (const double*)d_xyz, n, dim, k, include_self, d_idx_out, (double*)d_dist_out);
+    if (rc) return rc;
+    return sync(ctx);
+}
+
+WTP_API int wtp_knn(wtp_ctx* ctx, const void* xyz, int64_t n, int dim, int dtype, int k, int include_self,
+            int32_t* idx_out, void* dist_out) {
+    int rc = check_cloud(ctx, xyz, n, dim, dtype);
+    if (rc) return rc;
+    if ((rc = check_k(ctx, n, k, include_self))) return rc;
+    if ((rc = check_idle(ctx))) return rc;
+    if (!idx_out) return fail(ctx, WTP_ERR_ARG, "idx_out is NULL");
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t ts = tsize(dtype);
+    if ((rc = ensure(ctx, ctx->raw_in, ts * (size_t)n * dim))) return rc;
+    if ((rc = ensure(ctx, ctx->idx_out, sizeof(int32_t) * (size_t)n * k))) return rc;
+    if (dist_out && (rc = ensure(ctx, ctx->dist_out, ts * (size_t)n * k))) return rc;
+    WTP_HIP(ctx, hipMemcpyAsync(ctx->raw_in.p, xyz, ts * (size_t)n * dim, hipMemcpyHostToDevice, ctx->stream));
+    void* ddist = dist_out ? ctx->dist_out.p : nullptr;
+    if (dtype == WTP_F32)
+        rc = knn_dev_t<float>(ctx, (const float*)ctx->raw_in.p, n, dim, k, include_self, (int32_t*)ctx->idx_out.p,
+                              (float*)ddist);
+    else
+        rc = knn_dev_t<double>(ctx, (const double*)ctx->raw_in.p, n, dim, k, include_self,
+                               (int32_t*)ctx->idx_out.p, (double*)ddist);
+    if (rc) return rc;
+    WTP_HIP(ctx, hipMemcpyAsync(idx_out, ctx->idx_out.p, sizeof(int32_t) * (size_t)n * k, hipMemcpyDeviceToHost,
+                                ctx->stream));
+    if (dist_out)
+        WTP_HIP(ctx, hipMemcpyAsync(dist_out, ctx->dist_out.p, ts * (size_t)n * k, hipMemcpyDeviceToHost, ctx->stream));
+    return sync(ctx);
+}
+
+// ---- RadiusTopology ------------------------------------------------------------------------------
+template <typename T> static int radius_count_t(wtp_ctx* ctx, int64_t n, int dim, double r, int32_t* d_counts) {
+    int rc;
+    if ((rc = ensure(ctx, ctx->pts[0], sizeof(Pt<T>) * (size_t)n))) return rc;
+    if ((rc = ensure(ctx, ctx->pts[1], sizeof(Pt<T>) * (size_t)n))) return rc;
+    Pt<T>* raw = (Pt<T>*)ctx->pts[0].p;
+    Pt<T>* sorted = (Pt<T>*)ctx->pts[1].p;
+    int sp = span_begin(ctx, 0);
+    if ((rc = load_points<T>(ctx, (const T*)ctx->raw_in.p, raw, n, dim))) return rc;
+    if ((rc = build_hash<T>(ctx, raw, sorted, n, dim, 0, r > 0 ? r : 1e-300))) return rc;
+    span_end(ctx, sp);
+    SearchArgs<T> a{};
+    a.grid = (const Grid<T>*)ctx->grid.p;
+    a.snap = sorted;
+    a.query = sorted;
+    a.cell_start = (const int32_t*)ctx->cell_start.p;
+    a.n = (int32_t)n;
+    sp = span_begin(ctx, 1);
+    rc = launch_radius_count<T>(ctx, a, (T)r, d_counts);
+    span_end(ctx, sp);
+    return rc;
+}
+
+template <typename T> static int radius_fill_t(wtp_ctx* ctx, const int64_t* d_off, int32_t* d_idx) {
+    SearchArgs<T> a{};
+    a.grid = (const Grid<T>*)ctx->grid.p;
+    a.snap = (const Pt<T>*)ctx->pts[1].p;
+    a.query = a.snap;
+    a.cell_start = (const int32_t*)ctx->cell_start.p;
+    a.n = (int32_t)ctx->rad_n;
+    int sp = span_begin(ctx, 1);
+    int rc = launch_radius_fill<T>(ctx, a, (T)ctx->rad_r, d_off, d_idx);
+    span_end(ctx, sp);
+    return rc;
+}
+
+WTP_API int wtp_radius_count(wtp_ctx* ctx, const void* xyz, int64_t n, int dim, int dtype, double r, int32_t* counts_out) {
+    int rc = check_cloud(ctx, xyz, n, dim, dtype);
+    if (rc) return rc;
+    if (!(r >= 0) || !std::isfinite(r)) return fail(ctx, WTP_ERR_ARG, "radius must be finite and >= 0");
+    if (!counts_out) return fail(ctx, WTP_ERR_ARG, "counts_out is NULL");
+    if ((rc = check_idle(ctx))) return rc;
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t ts = tsize(dtype);
+    ctx->rad_valid = false;
+    ctx->relax.have_tree = false;
+    if ((rc = ensure(ctx, ctx->raw_in, ts * (size_t)n * dim))) return rc;
+    if ((rc = ensure(ctx, ctx->counts_out, sizeof(int32_t) * (size_t)n))) return rc;
+    WTP_HIP(ctx, hipMemcpyAsync(ctx->raw_in.p, xyz, ts * (size_t)n * dim, hipMemcpyHostToDevice, ctx->stream));
+    rc = dtype == WTP_F32 ? radius_count_t<float>(ctx, n, dim, r, (int32_t*)ctx->counts_out.p)
+                          : radius_count_t<double>(ctx, n, dim, r, (int32_t*)ctx->counts_out.p);
+    if (rc) return rc;
+    WTP_HIP(ctx, hipMemcpyAsync(counts_out, ctx->counts_out.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost,
+                                ctx->stream));
+    if ((rc = sync(ctx))) return rc;
+    ctx->rad_n = n;
+    ctx->rad_dim = dim;
+    ctx->rad_dtype = dtype;
+    ctx->rad_r = r;
+    ctx->rad_valid = true;
+    return WTP_OK;
+}
+
+WTP_API int wtp_radius_fill(wtp_ctx* ctx, const int64_t* offsets, int32_t* idx_out) {
+    if (!ctx) return WTP_ERR_ARG;
+    if (!ctx->rad_valid) return fail(ctx, WTP_ERR_STATE, "wtp_radius_fill needs a preceding wtp_radius_count");
+    if (!offsets) return fail(ctx, WTP_ERR_ARG, "offsets is NULL");
+    const int64_t n = ctx->rad_n;
+    if (offsets[0] != 0) return fail(ctx, WTP_ERR_ARG, "offsets[0] must be 0");
+    for (int64_t i = 0; i < n; ++i)
+        if (offsets[i + 1] < offsets[i]) return fail(ctx, WTP_ERR_ARG, "offsets must be non-decreasing");
+    const int64_t nnz = offsets[n];
+    if (nnz > 0 && !idx_out) return fail(ctx, WTP_ERR_ARG, "idx_out is NULL");
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t ts = tsize(ctx->rad_dtype);
+    int rc;
+    if ((rc = ensure(ctx, ctx->idx_out, sizeof(int32_t) * (size_t)(nnz + 1)))) return rc;
+    if ((rc = ensure(ctx, ctx->scratch, ts * (size_t)(nnz + 1)))) return rc;
+    if ((rc = ensure(ctx, ctx->dist_out, sizeof(int64_t) * (size_t)(n + 1)))) return rc; // offsets staging
+    WTP_HIP(ctx, hipMemcpyAsync(ctx->dist_out.p, offsets, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyHostToDevice,
+                                ctx->stream));
+    rc = ctx->rad_dtype == WTP_F32 ? radius_fill_t<float>(ctx, (const int64_t*)ctx->dist_out.p, (int32_t*)ctx->idx_out.p)
+                                   : radius_fill_t<double>(ctx, (const int64_t*)ctx->dist_out.p, (int32_t*)ctx->idx_out.p);
+    if (rc) return rc;
+    if (nnz > 0)
+        WTP_HIP(ctx, hipMemcpyAsync(idx_out, ctx->idx_out.p, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost,
+                                    ctx->stream));
+    return sync(ctx);
+}
+
+// ---- repel ------------------------------------------------------------------------------------------
+static int pick_free(const RelaxState& r, int avoid_a, int avoid_b) {
+    for (int i = 0; i < 3; ++i)
+        if (i != avoid_a && i != avoid_b) return i;
+    (void)r;
+    return 0;
+}
+
+WTP_API int wtp_relax_init(wtp_ctx* ctx, const void* snap_xyz, int64_t n, int64_t n_fixed, int dim, int dtype,
+                   const wtp_spacing_desc* spacing, const wtp_force_desc* force, int k, double alpha_lo,
+                   double alpha_max) {
+    int rc = check_cloud(ctx, snap_xyz, n, dim, dtype);
+    if (rc) return rc;
+    if (n_fixed < 0 || n_fixed > n) return fail(ctx, WTP_ERR_ARG, "n_fixed must be in [0, n]");
+    if (!spacing || !force) return fail(ctx, WTP_ERR_ARG, "spacing/force descriptor is NULL");
+    if (k < 1) return fail(ctx, WTP_ERR_ARG, "k must be >= 1");
+    if (force->kind < 0 || force->kind > 3) return fail(ctx, WTP_ERR_ARG, "unknown force kind");
+    if (!(force->beta > 0)) return fail(ctx, WTP_ERR_ARG, "force beta must be > 0");
+    if (spacing->kind == WTP_SPACING_CONSTANT) {
+        if (!(spacing->constant > 0)) return fail(ctx, WTP_ERR_ARG, "constant spacing must be > 0");
+    } else if (spacing->kind == WTP_SPACING_PER_POINT) {
+        if (!spacing->per_point) return fail(ctx, WTP_ERR_ARG, "per_point spacing array is NULL");
+    } else {
+        return fail(ctx, WTP_ERR_ARG, "unknown spacing kind");
+    }
+    if (!(alpha_lo >= 0) || !(alpha_max >= alpha_lo)) return fail(ctx, WTP_ERR_ARG, "need 0 <= alpha_lo <= alpha_max");
+    const int kk = (int64_t)k < n ? k : (int)n; // kk = min(k, length(snap)), src/repel.jl:208
+    if (kk > kGenericKMax) return fail(ctx, WTP_ERR_ARG, "k > 128 is not supported");
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t ts = tsize(dtype);
+    const size_t ptsz = dtype == WTP_F32 ? sizeof(float4) : sizeof(double4);
+    RelaxState& r = ctx->relax;
+    r = RelaxState{};
+    ctx->rad_valid = false;
+    for (int i = 0; i < 2; ++i)
+        if ((rc = ensure(ctx, ctx->pts[i], ptsz * (size_t)n))) return rc;
+    if ((rc = ensure(ctx, ctx->raw_in, ts * (size_t)n * dim))) return rc;
+    if ((rc = ensure(ctx, ctx->forces, ts * (size_t)n))) return rc;
+    if ((rc = ensure(ctx, ctx->nn_dist, ts * (size_t)n))) return rc;
+    if ((rc = ensure(ctx, ctx->nn_id, sizeof(int32_t) * (size_t)n))) return rc;
+    if ((rc = ensure(ctx, ctx->fb_list, sizeof(int32_t) * (size_t)n))) return rc;
+    if ((rc = ensure(ctx, ctx->fb_count, 64))) return rc;
+    const int n_partials = brick_partials() + kGenericPartials;
+    if ((rc = ensure(ctx, ctx->partials, sizeof(Partial) * (size_t)n_partials))) return rc;
+    WTP_HIP(ctx, hipMemcpyAsync(ctx->raw_in.p, snap_xyz, ts * (size_t)n * dim, hipMemcpyHostToDevice, ctx->stream));
+    if (dtype == WTP_F32)
+        rc = load_points<float>(ctx, (const float*)ctx->raw_in.p, (float4*)ctx->pts[0].p, n, dim);
+    else
+        rc = load_points<double>(ctx, (const double*)ctx->raw_in.p, (double4*)ctx->pts[0].p, n, dim);
+    if (rc) return rc;
+    if (spacing->kind == WTP_SPACING_PER_POINT) {
+        if ((rc = ensure(ctx, ctx->spacing_pp, ts * (size_t)n))) return rc;
+        WTP_HIP(ctx, hipMemcpyAsync(ctx->spacing_pp.p, spacing->per_point, ts * (size_t)n, hipMemcpyHostToDevice,
+                                    ctx->stream));
+    }
+    if ((rc = sync(ctx))) return rc;
+    r.active = true;
+    r.n = n;
+    r.n_fixed = n_fixed;
+    r.dim = dim;
+    r.dtype = dtype;
+    r.k = kk;
+    r.spacing_kind = spacing->kind;
+    r.spacing_const = spacing->constant;
+    r.alpha_lo = alpha_lo;
+    r.alpha_max = alpha_max;
+    r.force.kind = force->kind;
+    r.force.beta = force->beta;
+    r.force.u0 = force->u0;
+    r.force.gamma = force->gamma;
+    r.bufP = 0;
+    r.bufS = -1;
+    r.bufOld = -1;
+    return WTP_OK;
+}
+
+template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_step_stats* d_slot) {
+    RelaxState& r = ctx->relax;
+    int rc;
+    if (!r.have_tree) rebuild = 1; // the reference builds its first tree in the setup (src/repel.jl:218)
+    if (rebuild) {
+        // snapshot tail <- p, tree rebuilt (src/repel.jl:245-253): scatter P into a free buffer
+        const int t = pick_free(r, r.bufP, -1);
+        if ((rc = ensure(ctx, ctx->pts[t], sizeof(Pt<T>) * (size_t)r.n))) return rc;
+        int sp = span_begin(ctx, 0);
+        rc = build_hash<T>(ctx, (const Pt<T>*)ctx->pts[r.bufP].p, (Pt<T>*)ctx->pts[t].p, r.n, r.dim, r.k, 0.0);
+        span_end(ctx, sp);
+        if (rc) return rc;
+        r.bufS = t;
+        r.bufP = t;
+        r.have_tree = true;
+    }
+    const bool fresh = (r.bufS == r.bufP);
+    const int o = pick_free(r, r.bufS, r.bufP);
+    if ((rc = ensure(ctx, ctx->pts[o], sizeof(Pt<T>) * (size_t)r.n))) return rc;
+    SearchArgs<T> a{};
+    a.grid = (const Grid<T>*)ctx->grid.p;
+    a.snap = (const Pt<T>*)ctx->pts[r.bufS].p;
+    a.query = (const Pt<T>*)ctx->pts[r.bufP].p;
+    a.cell_start = (const int32_t*)ctx->cell_start.p;
+    a.n = (int32_t)r.n;
+    a.k = r.k;
+    a.include_self = 1;
+    a.out = (Pt<T>*)ctx->pts[o].p;
+    a.forces = (T*)ctx->forces.p;
+    a.nn_dist = (T*)ctx->nn_dist.p;
+    a.nn_id = (int32_t*)ctx->nn_id.p;
+    a.spacing_pp = r.spacing_kind == WTP_SPACING_PER_POINT ? (const T*)ctx->spacing_pp.p : nullptr;
+    a.spacing_const = (T)r.spacing_const;
+    a.alpha_lo = (T)r.alpha_lo;
+    a.alpha_max = (T)r.alpha_max;
+    a.beta = (T)r.force.beta;
+    a.u0 = (T)r.force.u0;
+    a.gamma = (T)r.force.gamma;
+    a.force_kind = r.force.kind;
+    a.n_fixed = (int32_t)r.n_fixed;
+    a.partials = (Partial*)ctx->partials.p;
+    a.n_partials = brick_partials() + kGenericPartials;
+    a.fb_list = (int32_t*)ctx->fb_list.p;
+    a.fb_count = (int32_t*)ctx->fb_count.p;
+    if ((rc = launch_sweep<T>(ctx, a, fresh))) return rc;
+    int sp = span_begin(ctx, 2);
+    rc = launch_reduce_partials(ctx, a.partials, a.n_partials, a.fb_count, d_slot);
+    span_end(ctx, sp);
+    if (rc) return rc;
+    r.bufOld = r.bufP; // p_old (src/repel.jl:244)
+    r.bufP = o;
+    r.can_revert = true;
+    r.have_point_data = true;
+    return WTP_OK;
+}
+
+static int relax_step_any(wtp_ctx* ctx, int rebuild, wtp_step_stats* d_slot) {
+    return ctx->relax.dtype == WTP_F32 ? relax_step_t<float>(ctx, rebuild, d_slot)
+                                       : relax_step_t<double>(ctx, rebuild, d_slot);
+}
+
+WTP_API int wtp_relax_step(wtp_ctx* ctx, int rebuild, wtp_step_stats* stats) {
+    if (!ctx) return WTP_ERR_ARG;
+    if (!ctx->relax.active) return fail(ctx, WTP_ERR_STATE, "wtp_relax_step before wtp_relax_init");
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, ctx->stats, sizeof(wtp_step_stats)))) return rc;
+    if ((rc = relax_step_any(ctx, rebuild, (wtp_step_stats*)ctx->stats.p))) return rc;
+    if (stats) {
+        if ((rc = ensure_pinned(ctx, sizeof(wtp_step_stats)))) return rc;
+        WTP_HIP(ctx, hipMemcpyAsync(ctx->host_pinned, ctx->stats.p, sizeof(wtp_step_stats), hipMemcpyDeviceToHost,
+                                    ctx->stream));
+        if ((rc = sync(ctx))) return rc;
+        memcpy(stats, ctx->host_pinned, sizeof(wtp_step_stats));
+        return WTP_OK;
+    }
+    return sync(ctx);
+}
+
+WTP_API int wtp_relax_run(wtp_ctx* ctx, int n_iters, int rebuild_every, double* conv_out, wtp_step_stats* last) {
+    if (!ctx) return WTP_ERR_ARG;
+    if (!ctx->relax.active) return fail(ctx, WTP_ERR_STATE, "wtp_relax_run before wtp_relax_init");
+    if (rebuild_every < 1) return fail(ctx, WTP_ERR_ARG, "rebuild_every must be >= 1"); // src/repel.jl:74
+    if (n_iters < 0) return fail(ctx, WTP_ERR_ARG, "n_iters must be >= 0");
+    if (n_iters == 0) return WTP_OK;
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, ctx->stats, sizeof(wtp_step_stats) * (size_t)n_iters))) return rc;
+    wtp_step_stats* d = (wtp_step_stats*)ctx->stats.p;
+    for (int i = 0; i < n_iters; ++i)
+        if ((rc = relax_step_any(ctx, (i % rebuild_every) == 0, d + i))) return rc;
+    if (conv_out || last) {
+        if ((rc = ensure_pinned(ctx, sizeof(wtp_step_stats) * (size_t)n_iters))) return rc;
+        WTP_HIP(ctx, hipMemcpyAsync(ctx->host_pinned, d, sizeof(wtp_step_stats) * (size_t)n_iters,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+        if ((rc = sync(ctx))) return rc;
+        const wtp_step_stats* h = (const wtp_step_stats*)ctx->host_pinned;
+        if (conv_out)
+            for (int i = 0; i < n_iters; ++i) conv_out[i] = h[i].max_force;
+        if (last) *last = h[n_iters - 1];
+        return WTP_OK;
+    }
+    return sync(ctx);
+}
+
+WTP_API int wtp_relax_get(wtp_ctx* ctx, void* xyz_out) {
+    if (!ctx) return WTP_ERR_ARG;
+    RelaxState& r = ctx->relax;
+    if (!r.active) return fail(ctx, WTP_ERR_STATE, "wtp_relax_get before wtp_relax_init");
+    if (!xyz_out) return fail(ctx, WTP_ERR_ARG, "xyz_out is NULL");
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t n_move = r.n - r.n_fixed;
+    if (n_move == 0) return WTP_OK;
+    const size_t bytes = tsize(r.dtype) * (size_t)n_move * r.dim;
+    int rc;
+    if ((rc = ensure(ctx, ctx->scratch, bytes))) return rc;
+    if (r.dtype == WTP_F32)
+        rc = launch_unpermute<float>(ctx, (const float4*)ctx->pts[r.bufP].p, r.n, r.n_fixed, r.dim, (float*)ctx->scratch.p);
+    else
+        rc = launch_unpermute<double>(ctx, (const double4*)ctx->pts[r.bufP].p, r.n, r.n_fixed, r.dim, (double*)ctx->scratch.p);
+    if (rc) return rc;
+    WTP_HIP(ctx, hipMemcpyAsync(xyz_out, ctx->scratch.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return sync(ctx);
+}
+
+WTP_API int wtp_relax_get_point_data(wtp_ctx* ctx, void* forces_out, void* nn_dist_out, int32_t* nn_id_out) {
+    if (!ctx) return WTP_ERR_ARG;
+    RelaxState& r = ctx->relax;
+    if (!r.active || !r.have_point_data || r.bufOld < 0)
+        return fail(ctx, WTP_ERR_STATE, "wtp_relax_get_point_data needs a completed wtp_relax_step");
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t n_move = r.n - r.n_fixed;
+    if (n_move == 0) return WTP_OK;
+    const size_t ts = tsize(r.dtype);
+    int rc;
+    if ((rc = ensure(ctx, ctx->scratch, (2 * ts + 4) * (size_t)n_move))) return rc;
+    char* base = (char*)ctx->scratch.p;
+    void* fo = base;
+    void* no = base + ts * n_move;
+    int32_t* io = (int32_t*)(base + 2 * ts * n_move);
+    // per-point arrays are in the slot order of the sweep's query buffer (== bufOld)
+    if (r.dtype == WTP_F32)
+        rc = launch_unpermute_point_data<float>(ctx, (const float4*)ctx->pts[r.bufOld].p, r.n, r.n_fixed,
+                                                (const float*)ctx->forces.p, (const float*)ctx->nn_dist.p,
+                                                (const int32_t*)ctx->nn_id.p, (float*)fo, (float*)no, io);
+    else
+        rc = launch_unpermute_point_data<double>(ctx, (const double4*)ctx->pts[r.bufOld].p, r.n, r.n_fixed,
+                                                 (const double*)ctx->forces.p, (const double*)ctx->nn_dist.p,
+                                                 (const int32_t*)ctx->nn_id.p, (double*)fo, (double*)no, io);
+    if (rc) return rc;
+    if (forces_out) WTP_HIP(ctx, hipMemcpyAsync(forces_out, fo, ts * n_move, hipMemcpyDeviceToHost, ctx->stream));
+    if (nn_dist_out) WTP_HIP(ctx, hipMemcpyAsync(nn_dist_out, no, ts * n_move, hipMemcpyDeviceToHost, ctx->stream));
+    if (nn_id_out) WTP_HIP(ctx, hipMemcpyAsync(nn_id_out, io, 4 * (size_t)n_move, hipMemcpyDeviceToHost, ctx->stream));
+    return sync(ctx);
+}
+
+WTP_API int wtp_relax_set(wtp_ctx* ctx, int64_t i, const void* xyz) {
+    if (!ctx) return WTP_ERR_ARG;
+    RelaxState& r = ctx->relax;
+    if (!r.active) return fail(ctx, WTP_ERR_STATE, "wtp_relax_set before wtp_relax_init");
+    if (!xyz) return fail(ctx, WTP_ERR_ARG, "xyz is NULL");
+    if (i < 0 || i >= r.n - r.n_fixed) return fail(ctx, WTP_ERR_ARG, "movable point index out of range");
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t ts = tsize(r.dtype);
+    int rc;
+    if ((rc = ensure(ctx, ctx->scratch, 64))) return rc;
+    // P may alias the snapshot (fresh tree): the kick must not move the tree's copy, so give P
+    // its own buffer first.
+    if (r.bufP == r.bufS) {
+        const int t = pick_free(r, r.bufS, r.can_revert ? r.bufOld : -1);
+        if (t == r.bufS) return fail(ctx, WTP_ERR_STATE, "no free buffer for wtp_relax_set");
+        const size_t ptsz = r.dtype == WTP_F32 ? sizeof(float4) : sizeof(double4);
+        if ((rc = ensure(ctx, ctx->pts[t], ptsz * (size_t)r.n))) return rc;
+        WTP_HIP(ctx, hipMemcpyAsync(ctx->pts[t].p, ctx->pts[r.bufP].p, ptsz * (size_t)r.n, hipMemcpyDeviceToDevice,
+                                    ctx->stream));
+        if (r.bufOld == t) r.can_revert = false;
+        r.bufP = t;
+    }
+    WTP_HIP(ctx, hipMemcpyAsync(ctx->scratch.p, xyz, ts * r.dim, hipMemcpyHostToDevice, ctx->stream));
+    const int32_t id = (int32_t)(i + r.n_fixed);
+    if (r.dtype == WTP_F32)
+        rc = launch_set_point<float>(ctx, (float4*)ctx->pts[r.bufP].p, r.n, id, r.dim, (const float*)ctx->scratch.p);
+    else
+        rc = launch_set_point<double>(ctx, (double4*)ctx->pts[r.bufP].p, r.n, id, r.dim, (const double*)ctx->scratch.p);
+    if (rc) return rc;
+    return sync(ctx);
+}
+
+WTP_API int wtp_relax_revert(wtp_ctx* ctx) {
+    if (!ctx) return WTP_ERR_ARG;
+    RelaxState& r = ctx->relax;
+    if (!r.active || !r.can_revert || r.bufOld < 0)
+        return fail(ctx, WTP_ERR_STATE, "wtp_relax_revert needs a wtp_relax_step to undo");
+    r.bufP = r.bufOld; // p .= p_old (src/repel.jl:314)
+    r.can_revert = false;
+    return WTP_OK;
+}
+
+WTP_API int wtp_relax_set_spacing(wtp_ctx* ctx, const void* spacing) {
+    if (!ctx) return WTP_ERR_ARG;
+    RelaxState& r = ctx->relax;
+    if (!r.active) return fail(ctx, WTP_ERR_STATE, "wtp_relax_set_spacing before wtp_relax_init");
+    if (r.spacing_kind != WTP_SPACING_PER_POINT) return fail(ctx, WTP_ERR_STATE, "spacing is not PER_POINT");
+    if (!spacing) return fail(ctx, WTP_ERR_ARG, "spacing is NULL");
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    WTP_HIP(ctx, hipMemcpyAsync(ctx->spacing_pp.p, spacing, tsize(r.dtype) * (size_t)r.n, hipMemcpyHostToDevice,
+                                ctx->stream));
+    return sync(ctx);
+}
+
+WTP_API int wtp_relax_end(wtp_ctx* ctx) {
+    if (!ctx) return WTP_ERR_ARG;
+    ctx->relax = RelaxState{};
+    return WTP_OK;
+}
+
+WTP_API int wtp_timers_get(wtp_ctx* ctx, double out[4]) {
+    if (!ctx || !out) return WTP_ERR_ARG;
+    hipSetDevice(ctx->device);
+    spans_collect(ctx);
+    out[0] = ctx->t_hash;
+    out[1] = ctx->t_sweep;
+    out[2] = ctx->t_other;
+    out[3] = (double)ctx->n_sweep_launches;
+    return WTP_OK;
+}
+
+WTP_API int wtp_timers_reset(wtp_ctx* ctx) {
+    if (!ctx) return WTP_ERR_ARG;
+    hipSetDevice(ctx->device);
+    spans_collect(ctx);
+    ctx->t_hash = ctx->t_sweep = ctx->t_other = 0;
+    ctx->n_sweep_launches = 0;
+    return WTP_OK;
+}
+
+// ---- device-side helpers for bench.py / the sharded driver (not part of the drop-in surface) -----
+WTP_API int wtp_gen_uniform_dev(wtp_ctx* ctx, uint64_t seed, int64_t first, int64_t n, int dim, int dtype, void* d_out) {
+    if (!ctx || !d_out || n < 0) return WTP_ERR_ARG;
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = dtype == WTP_F32 ? launch_gen_uniform<float>(ctx, seed, first, n, dim, (float*)d_out)
+                              : launch_gen_uniform<double>(ctx, seed, first, n, dim, (double*)d_out);
+    if (rc) return rc;
+    return sync(ctx);
+}
+

@@ -1,0 +1,415 @@
+// wtp_brick.hip — the hot kernels: 27-cell k-NN with the candidates staged in LDS (gfx950, fp32).
+//
+// One 256-thread workgroup sweeps a brick of BX x BY x BZ cells.  It stages the brick's
+// (BX+2)(BY+2)(BZ+2) halo cells from the sorted Pt array into LDS (16-B ds_read_b128 per
+// candidate afterwards), then every lane owns one query at a time:
+//   scan      the 9 x-rows of its 3x3x3 neighbourhood; candidates with d2 <= tau are appended
+//             (LDS slot, 16 bit) to a per-lane ring in LDS.  tau starts at
+//             min(provable radius, gamma_cap * cell)^2, so whatever is kept is exact.
+//   select    keys (d2 bit patterns, monotone for d2 >= 0) go through a 64-wide Batcher
+//             network held in VGPRs; the k-th key is the cut.
+//   topology  MODE 0: 64-bit keys (d2 bits << 32 | id) sort the survivors canonically and the
+//             first k are written as the row of the query's original id
+//             (_build_knn_neighbors, src/topology.jl:79-84).
+//   sweep     MODE 1: the Miotti force of src/repel.jl:270-291 is accumulated over the cut set
+//             in the same pass structure, the point is stepped, and max|F|s, sum u, sum u^2
+//             and the closest pair are reduced per wave with shuffles (src/repel.jl:293,374-403).
+// Queries the fast path cannot certify (k-th hit beyond the provable radius, a tie exactly at
+// the cut, ring overflow, halo larger than LDS) are appended to a work list for
+// wtp_generic.hip; results are therefore always the exact canonical lists.
+//
+// Roofline: this kernel streams 16 B/point in and 28 B/point out (MODE 1) — its HBM floor is
+// ~0.07 ms for 10 M points — but does ~5-6 k VALU lane-ops per query, so it is bound by the
+// vector ALU and LDS issue rate, not by HBM.
+#include "wtp_device.hpp"
+#include "wtp_sortnet.hpp"
+
+namespace wtp {
+
+constexpr int NB = 64;          // per-lane candidate ring / sorting-network width
+constexpr int kFastKMax = 48;   // k beyond this goes to the generic kernel
+constexpr int kOwnRows = BY * BZ;
+
+struct BrickSmem {
+    int hstart[HCELLS + 1];   // LDS slot of the first point of each halo cell
+    int hglobal[HCELLS];      // global (sorted) index of the first point of each halo cell
+    int own_pref[kOwnRows + 1];
+    int scan_tmp[kBrickThreads / 64 + 1];
+    Acc acc[kBrickThreads / 64];
+};
+
+#define WTP_CE(k, i, j)                      \
+    {                                        \
+        auto lo_ = k[i] < k[j] ? k[i] : k[j];\
+        auto hi_ = k[i] < k[j] ? k[j] : k[i];\
+        k[i] = lo_;                          \
+        k[j] = hi_;                          \
+    }
+
+__device__ inline uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+__device__ inline float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+
+// d2 of ring entry j of this lane, +inf bits when j >= cnt
+__device__ inline uint32_t ring_key(const float4* __restrict__ pts, const uint16_t* __restrict__ ring, int j,
+                                    int cnt, float qx, float qy, float qz) {
+    if (j >= cnt) return 0x7F800000u;
+    const float4 c = pts[ring[j * kBrickThreads]];
+    return f2u(dist2<float>(qx, qy, qz, c.x, c.y, c.z));
+}
+
+// Sort this lane's ring keys; return k-th smallest (index K-1) and the next one (index K).
+__device__ inline void ring_select(const float4* __restrict__ pts, const uint16_t* __restrict__ ring, int cnt,
+                                   float qx, float qy, float qz, int K, uint32_t& kth, uint32_t& next) {
+    uint32_t k[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) k[j] = ring_key(pts, ring, j, cnt, qx, qy, qz);
+    WTP_SORTNET_64(k)
+    kth = k[0];
+    next = k[1];
+#pragma unroll
+    for (int j = 1; j < NB - 1; ++j) {
+        kth = (j == K - 1) ? k[j] : kth;
+        next = (j == K - 1) ? k[j + 1] : next;
+    }
+}
+
+// Tighten tau to the k-th smallest so far and drop ring entries beyond it.
+__device__ inline void ring_prune(const float4* __restrict__ pts, uint16_t* __restrict__ ring, int& cnt,
+                                  float& tau, float qx, float qy, float qz, int K) {
+    uint32_t kth, next;
+    ring_select(pts, ring, cnt, qx, qy, qz, K, kth, next);
+    if (cnt >= K) {
+        const float t = u2f(kth);
+        tau = t < tau ? t : tau;
+    }
+    int keep = 0;
+#pragma unroll 4
+    for (int j = 0; j < NB; ++j) {
+        if (j < cnt) {
+            const uint16_t s = ring[j * kBrickThreads];
+            const float4 c = pts[s];
+            const float d = dist2<float>(qx, qy, qz, c.x, c.y, c.z);
+            if (d <= tau) {
+                ring[keep * kBrickThreads] = s;
+                ++keep;
+            }
+        }
+    }
+    cnt = keep;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBrickThreads) void brick_kernel(SearchArgs<float> a, int hcap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float4* pts = reinterpret_cast<float4*>(smem_raw);
+    uint16_t* ring_all = reinterpret_cast<uint16_t*>(smem_raw + (size_t)hcap * sizeof(float4));
+    BrickSmem* sm = reinterpret_cast<BrickSmem*>(smem_raw + (size_t)hcap * sizeof(float4) +
+                                                 (size_t)NB * kBrickThreads * sizeof(uint16_t));
+    const int tid = threadIdx.x;
+    uint16_t* ring = ring_all + tid; // entry j at ring[j * kBrickThreads]
+
+    const Grid<float> g = *a.grid;
+    const int K = a.k;
+    const bool skip_self = (MODE == 0) && !a.include_self;
+    const float cap2 = (a.gamma_cap * g.c) * (a.gamma_cap * g.c);
+    Acc acc = acc_empty();
+
+    // XCD-aware brick order: blocks sharing blockIdx % 8 share an L2; give each such group one
+    // contiguous slab of bricks so halo re-reads of neighbouring bricks hit that L2.
+    const int groups = 8;
+    const int per = (g.nbricks + groups - 1) / groups;
+    const int xcd = blockIdx.x % groups;
+    const int lane_blk = blockIdx.x / groups;
+    const int blk_per_group = gridDim.x / groups;
+    const int b_end = (xcd + 1) * per < g.nbricks ? (xcd + 1) * per : g.nbricks;
+
+    for (int brick = xcd * per + lane_blk; brick < b_end; brick += blk_per_group) {
+        const int bx = brick % g.nb[0];
+        const int by = (brick / g.nb[0]) % g.nb[1];
+        const int bz = brick / (g.nb[0] * g.nb[1]);
+        const int ox = bx * BX - 1, oy = by * BY - 1, oz = bz * BZ - 1; // halo origin (cell coords)
+
+        __syncthreads(); // previous brick's LDS no longer in use
+        // ---- 1. halo cell table ---------------------------------------------------------
+        int my_cnt = 0;
+        if (tid < HCELLS) {
+            const int hx = tid % HX, hy = (tid / HX) % HY, hz = tid / (HX * HY);
+            const int gx = ox + hx, gy = oy + hy, gz = oz + hz;
+            int gs = 0;
+            if (gx >= 0 && gx < g.n[0] && gy >= 0 && gy < g.n[1] && gz >= 0 && gz < g.n[2]) {
+                const int cell = (gz * g.n[1] + gy) * g.n[0] + gx;
+                gs = a.cell_start[cell];
+                my_cnt = a.cell_start[cell + 1] - gs;
+            }
+            sm->hglobal[tid] = gs;
+        }
+        // block exclusive scan of my_cnt
+        {
+            int incl = my_cnt;
+            const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += o;
+            }
+            if (lane == 63) sm->scan_tmp[wave] = incl;
+            __syncthreads();
+            if (tid == 0) {
+                int run = 0;
+                for (int w = 0; w < kBrickThreads / 64; ++w) {
+                    const int t = sm->scan_tmp[w];
+                    sm->scan_tmp[w] = run;
+                    run += t;
+                }
+                sm->scan_tmp[kBrickThreads / 64] = run;
+            }
+            __syncthreads();
+            const int ex = incl - my_cnt + sm->scan_tmp[wave];
+            if (tid < HCELLS) sm->hstart[tid] = ex;
+            if (tid == HCELLS) sm->hstart[HCELLS] = sm->scan_tmp[kBrickThreads / 64];
+        }
+        __syncthreads();
+        const int halo_total = sm->hstart[HCELLS];
+        const bool overflow = halo_total > hcap;
+
+        // ---- 2. own-row prefix (queries = points of the BX*BY*BZ own cells) ------------------
+        if (tid == 0) {
+            int run = 0;
+            for (int r = 0; r < kOwnRows; ++r) {
+                const int hy = 1 + r % BY, hz = 1 + r / BY;
+                const int base = (hz * HY + hy) * HX;
+                sm->own_pref[r] = run;
+                run += sm->hstart[base + 1 + BX] - sm->hstart[base + 1];
+            }
+            sm->own_pref[kOwnRows] = run;
+        }
+        // ---- 3. stage halo points: each x-row of HX cells is one contiguous global run ----------
+        if (!overflow) {
+            const int wave = tid >> 6, lane = tid & 63;
+            const int hx_lo = ox < 0 ? -ox : 0; // first halo column inside the grid
+            for (int row = wave; row < HY * HZ; row += kBrickThreads / 64) {
+                const int base = row * HX;
+                const int ls = sm->hstart[base];
+                const int len = sm->hstart[base + HX] - ls;
+                if (len <= 0) continue;
+                const int gs = sm->hglobal[base + hx_lo];
+                for (int i = lane; i < len; i += 64) pts[ls + i] = a.snap[gs + i];
+            }
+        }
+        __syncthreads();
+
+        // ---- 4. queries -----------------------------------------------------------------------
+        const int Q = sm->own_pref[kOwnRows];
+        for (int qb = 0; qb < Q; qb += kBrickThreads) {
+            const int q = qb + tid;
+            const bool active = q < Q;
+            int r = 0;
+            if (active) {
+#pragma unroll
+                for (int t = 1; t < kOwnRows; ++t) r += (sm->own_pref[t] <= q) ? 1 : 0;
+            }
+            const int hy0 = 1 + r % BY, hz0 = 1 + r / BY;
+            const int rbase = (hz0 * HY + hy0) * HX + 1;
+            const int off = q - sm->own_pref[r];
+            const int gslot = sm->hglobal[rbase] + off; // index in the sorted arrays
+            if (!active) continue;
+            if (overflow) { // halo does not fit LDS: generic kernel takes the whole brick
+                const int pos = atomicAdd(a.fb_count, 1);
+                a.fb_list[pos] = gslot;
+                continue;
+            }
+            const float4 qp = pts[sm->hstart[rbase] + off];
+            const int32_t qid = w_to_id(qp.w);
+            if (MODE == 1 && qid < a.n_fixed) { // the wall: never moves (src/repel.jl:80,256)
+                a.out[gslot] = qp;
+                a.forces[gslot] = 0.f;
+                a.nn_dist[gslot] = Lim<float>::inf();
+                a.nn_id[gslot] = -1;
+                continue;
+            }
+            const int cx = cell_coord(g, qp.x, 0), cy = cell_coord(g, qp.y, 1), cz = cell_coord(g, qp.z, 2);
+            const int hx = cx - ox, hy = cy - oy, hz = cz - oz;
+            const float g2 = safe_radius2(g, qp.x, qp.y, qp.z, cx, cy, cz, 1);
+            float tau = g2 < cap2 ? g2 : cap2;
+            int cnt = 0;
+            bool giveup = false;
+
+#pragma unroll 1
+            for (int row = 0; row < 9; ++row) {
+                const int dz = row / 3 - 1, dy = row % 3 - 1;
+                const int base = ((hz + dz) * HY + (hy + dy)) * HX + (hx - 1);
+                const int s = sm->hstart[base], e = sm->hstart[base + 3];
+                for (int p = s; p < e; p += 4) {
+                    if (__any(cnt > NB - 4)) ring_prune(pts, ring, cnt, tau, qp.x, qp.y, qp.z, K);
+                    if (cnt > NB - 4) { // ring still full (mass tie): give up, go generic
+                        giveup = true;
+                        cnt = 0;
+                        tau = -1.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (p + u < e) {
+                            const float4 c = pts[p + u];
+                            const float d = dist2<float>(qp.x, qp.y, qp.z, c.x, c.y, c.z);
+                            const bool take = (d <= tau) && !(skip_self && w_to_id(c.w) == qid);
+                            if (take) {
+                                ring[cnt * kBrickThreads] = (uint16_t)(p + u);
+                                ++cnt;
+                            }
+                        }
+                    }
+                }
+            }
+
+            bool fallback = (cnt < K) || giveup;
+            if (MODE == 0) {
+                // canonical order: 64-bit key (d2 bits << 32 | id) over the survivors
+                uint64_t k[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    if (j < cnt) {
+                        const float4 c = pts[ring[j * kBrickThreads]];
+                        const uint32_t d = f2u(dist2<float>(qp.x, qp.y, qp.z, c.x, c.y, c.z));
+                        k[j] = ((uint64_t)d << 32) | (uint32_t)w_to_id(c.w);
+                    } else {
+                        k[j] = ~0ull;
+                    }
+                }
+                WTP_SORTNET_64(k)
+                if (!fallback) {
+                    int32_t* orow = a.idx_out + (int64_t)qid * K;
+                    float* drow = a.dist_out ? a.dist_out + (int64_t)qid * K : nullptr;
+#pragma unroll
+                    for (int j = 0; j < kFastKMax; ++j) {
+                        if (j < K) {
+                            orow[j] = (int32_t)(uint32_t)k[j];
+                            if (drow) drow[j] = wsqrt(u2f((uint32_t)(k[j] >> 32)));
+                        }
+                    }
+                }
+            } else {
+                uint32_t kth, next;
+                ring_select(pts, ring, cnt, qp.x, qp.y, qp.z, K, kth, next);
+                fallback = fallback || (kth == next && K < NB); // tie exactly at the cut
+                if (!fallback) {
+                    const float cut = u2f(kth);
+                    const float s = a.spacing_pp ? a.spacing_pp[qid] : a.spacing_const;
+                    float Fx = 0.f, Fy = 0.f, Fz = 0.f;
+                    int32_t nid = -1;
+                    float nd2 = Lim<float>::inf();
+                    for (int j = 0; j < cnt; ++j) {
+                        const float4 c = pts[ring[j * kBrickThreads]];
+                        const float d = dist2<float>(qp.x, qp.y, qp.z, c.x, c.y, c.z);
+                        const int32_t cid = w_to_id(c.w);
+                        if (d <= cut && cid != qid) { // the kk nearest, self skipped by index (:271)
+                            if (lex_lt(d, cid, nd2, nid < 0 ? 0x7FFFFFFF : nid)) {
+                                nd2 = d;
+                                nid = cid;
+                            }
+                            add_force<float>(a, g.dim, s, qp.x, qp.y, qp.z, qid, c.x, c.y, c.z, cid, d, Fx, Fy, Fz);
+                        }
+                    }
+                    float4 o;
+                    const float f = step_point<float>(a, s, qp.x, qp.y, qp.z, Fx, Fy, Fz, o.x, o.y, o.z);
+                    o.w = qp.w;
+                    const float nd = nid < 0 ? Lim<float>::inf() : wsqrt(nd2);
+                    a.out[gslot] = o;
+                    a.forces[gslot] = f;
+                    a.nn_dist[gslot] = nd;
+                    a.nn_id[gslot] = nid;
+                    acc_point(acc, (double)f, (double)nd, (double)s, qid, nid);
+                }
+            }
+            if (fallback) {
+                const int pos = atomicAdd(a.fb_count, 1);
+                a.fb_list[pos] = gslot;
+            }
+        }
+    }
+    if (MODE == 1) {
+        __syncthreads();
+        acc_block_reduce(acc, sm->acc);
+        if (tid == 0) acc_store(&a.partials[blockIdx.x], acc);
+    }
+}
+
+static size_t brick_smem_bytes(int hcap) {
+    return (size_t)hcap * sizeof(float4) + (size_t)NB * kBrickThreads * sizeof(uint16_t) + sizeof(BrickSmem);
+}
+
+// LDS budget: 160 KiB per CU; hcap sized so two workgroups fit.
+static int pick_hcap() { return 2560; }
+
+template <int MODE> static int brick_grid(wtp_ctx* ctx, int hcap) {
+    int occ = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, brick_kernel<MODE>, kBrickThreads,
+                                                                brick_smem_bytes(hcap));
+    if (e != hipSuccess || occ < 1) occ = 1;
+    if (occ > 4) occ = 4;
+    int gsz = ctx->sm_count * occ;
+    gsz -= gsz % 8;
+    return gsz < 8 ? 8 : gsz;
+}
+
+int brick_partials() { return 256 * 4 + 8; }
+
+template <> int launch_topology<float>(wtp_ctx* ctx, SearchArgs<float>& a) {
+    if (a.k > kFastKMax || ctx->force_generic) return launch_generic_topology<float>(ctx, a, true);
+    const int hcap = pick_hcap();
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)brick_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)brick_smem_bytes(hcap));
+        attr_set = true;
+    }
+    a.gamma_cap = (float)ctx->gamma_cap;
+    WTP_HIP(ctx, hipMemsetAsync(a.fb_count, 0, sizeof(int32_t), ctx->stream));
+    const int gsz = brick_grid<0>(ctx, hcap);
+    hipLaunchKernelGGL(brick_kernel<0>, dim3(gsz), dim3(kBrickThreads), brick_smem_bytes(hcap), ctx->stream, a, hcap);
+    WTP_HIP(ctx, hipGetLastError());
+    return launch_generic_topology<float>(ctx, a, false);
+}
+
+template <> int launch_topology<double>(wtp_ctx* ctx, SearchArgs<double>& a) {
+    return launch_generic_topology<double>(ctx, a, true); // fp64: exact generic path
+}
+
+template <> int launch_sweep<float>(wtp_ctx* ctx, SearchArgs<float>& a, bool fresh) {
+    WTP_HIP(ctx, hipMemsetAsync(a.partials, 0, sizeof(Partial) * (size_t)a.n_partials, ctx->stream));
+    WTP_HIP(ctx, hipMemsetAsync(a.fb_count, 0, sizeof(int32_t), ctx->stream));
+    if (!fresh || a.k > kFastKMax || ctx->force_generic) {
+        const int sp = span_begin(ctx, 1);
+        int rc = launch_generic_sweep<float>(ctx, a, true);
+        span_end(ctx, sp);
+        return rc;
+    }
+    const int hcap = pick_hcap();
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)brick_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)brick_smem_bytes(hcap));
+        attr_set = true;
+    }
+    a.gamma_cap = (float)ctx->gamma_cap;
+    const int gsz = brick_grid<1>(ctx, hcap);
+    const int sp = span_begin(ctx, 1);
+    hipLaunchKernelGGL(brick_kernel<1>, dim3(gsz), dim3(kBrickThreads), brick_smem_bytes(hcap), ctx->stream, a, hcap);
+    span_end(ctx, sp);
+    ctx->n_sweep_launches += 1;
+    WTP_HIP(ctx, hipGetLastError());
+    const int sp2 = span_begin(ctx, 2);
+    int rc = launch_generic_sweep<float>(ctx, a, false);
+    span_end(ctx, sp2);
+    return rc;
+}
+
+template <> int launch_sweep<double>(wtp_ctx* ctx, SearchArgs<double>& a, bool) {
+    WTP_HIP(ctx, hipMemsetAsync(a.partials, 0, sizeof(Partial) * (size_t)a.n_partials, ctx->stream));
+    WTP_HIP(ctx, hipMemsetAsync(a.fb_count, 0, sizeof(int32_t), ctx->stream));
+    const int sp = span_begin(ctx, 1);
+    int rc = launch_generic_sweep<double>(ctx, a, true);
+    span_end(ctx, sp);
+    return rc;
+}
+
+} // namespace wtp

@@ -1,0 +1,208 @@
+// wtp_generic.hip — exact thread-per-query search over the cell grid with ring expansion.
+//
+// This is the always-correct path: it serves (a) queries the 27-cell brick kernels hand back
+// (k-th neighbour beyond the provable radius, LDS halo overflow, k too large for the register
+// network), (b) sweeps against a stale snapshot (rebuild_every > 1, src/repel.jl:245,262-266)
+// and (c) RadiusTopology (src/topology.jl:91-97), whose cell edge >= r makes 27 cells exact.
+// It follows the same canonical (d2, index) order as the oracle, and sums forces in ascending
+// order exactly like src/repel.jl:270-280.
+#include "wtp_device.hpp"
+
+namespace wtp {
+
+static constexpr int kThreads = 128;
+
+template <typename T, int MODE> // MODE 0: topology rows, 1: relax sweep
+__global__ __launch_bounds__(kThreads) void generic_kernel(SearchArgs<T> a, const int32_t* __restrict__ list,
+                                                           const int32_t* __restrict__ list_count,
+                                                           int all, int part_base) {
+    __shared__ Acc sm_acc[kThreads / 64];
+    const Grid<T> g = *a.grid;
+    const int nq = all ? a.n : *list_count;
+    const int K = a.k;
+    const bool skip_self = (MODE == 0) && !a.include_self;
+    T bd[kGenericKMax];
+    int32_t bi[kGenericKMax];
+    int32_t bp[kGenericKMax];
+    Acc acc = acc_empty();
+
+    for (int qi = blockIdx.x * blockDim.x + threadIdx.x; qi < nq; qi += gridDim.x * blockDim.x) {
+        const int slot = all ? qi : list[qi];
+        const Pt<T> q = a.query[slot];
+        const int32_t id = w_to_id(q.w);
+        if (MODE == 1 && id < a.n_fixed) {
+            a.out[slot] = q;
+            a.forces[slot] = (T)0;
+            a.nn_dist[slot] = Lim<T>::inf();
+            a.nn_id[slot] = -1;
+            continue;
+        }
+        const int cx = cell_coord(g, q.x, 0), cy = cell_coord(g, q.y, 1), cz = cell_coord(g, q.z, 2);
+        int m = 0;
+        for (int r = 1;; r *= 2) {
+            m = 0;
+            const int z0 = cz - r < 0 ? 0 : cz - r, z1 = cz + r > g.n[2] - 1 ? g.n[2] - 1 : cz + r;
+            const int y0 = cy - r < 0 ? 0 : cy - r, y1 = cy + r > g.n[1] - 1 ? g.n[1] - 1 : cy + r;
+            const int x0 = cx - r < 0 ? 0 : cx - r, x1 = cx + r > g.n[0] - 1 ? g.n[0] - 1 : cx + r;
+            for (int z = z0; z <= z1; ++z)
+                for (int y = y0; y <= y1; ++y) {
+                    const int row = (z * g.n[1] + y) * g.n[0];
+                    const int ps = a.cell_start[row + x0], pe = a.cell_start[row + x1 + 1];
+                    for (int p = ps; p < pe; ++p) {
+                        const Pt<T> c = a.snap[p];
+                        const int32_t cid = w_to_id(c.w);
+                        if (skip_self && cid == id) continue;
+                        const T d = dist2<T>(q.x, q.y, q.z, c.x, c.y, c.z);
+                        if (m == K && !lex_lt(d, cid, bd[K - 1], bi[K - 1])) continue;
+                        int pos = (m < K) ? m++ : K - 1;
+                        while (pos > 0 && lex_lt(d, cid, bd[pos - 1], bi[pos - 1])) {
+                            bd[pos] = bd[pos - 1];
+                            bi[pos] = bi[pos - 1];
+                            bp[pos] = bp[pos - 1];
+                            --pos;
+                        }
+                        bd[pos] = d;
+                        bi[pos] = cid;
+                        bp[pos] = p;
+                    }
+                }
+            const T g2 = safe_radius2(g, q.x, q.y, q.z, cx, cy, cz, r);
+            if (g2 == Lim<T>::inf()) break;          // searched block covers the grid
+            if (m == K && bd[K - 1] <= g2) break;    // k-th hit provably final
+        }
+
+        if (MODE == 0) {
+            int32_t* row = a.idx_out + (int64_t)id * K;
+            for (int j = 0; j < K; ++j) row[j] = j < m ? bi[j] : -1;
+            if (a.dist_out) {
+                T* drow = a.dist_out + (int64_t)id * K;
+                for (int j = 0; j < K; ++j) drow[j] = j < m ? wsqrt(bd[j]) : Lim<T>::inf();
+            }
+        } else {
+            const T s = a.spacing_pp ? a.spacing_pp[id] : a.spacing_const;
+            T Fx = 0, Fy = 0, Fz = 0;
+            int32_t nid = -1;
+            T nd = Lim<T>::inf();
+            for (int j = 0; j < m; ++j) { // ascending (d2, id): src/repel.jl:270-280
+                if (bi[j] == id) continue;
+                if (nid < 0) {
+                    nid = bi[j];
+                    nd = wsqrt(bd[j]);
+                }
+                const Pt<T> c = a.snap[bp[j]];
+                add_force<T>(a, g.dim, s, q.x, q.y, q.z, id, c.x, c.y, c.z, bi[j], bd[j], Fx, Fy, Fz);
+            }
+            Pt<T> o;
+            const T f = step_point<T>(a, s, q.x, q.y, q.z, Fx, Fy, Fz, o.x, o.y, o.z);
+            o.w = q.w;
+            a.out[slot] = o;
+            a.forces[slot] = f;
+            a.nn_dist[slot] = nd;
+            a.nn_id[slot] = nid;
+            acc_point(acc, (double)f, (double)nd, (double)s, id, nid);
+        }
+    }
+    if (MODE == 1) {
+        acc_block_reduce(acc, sm_acc);
+        if (threadIdx.x == 0) acc_store(&a.partials[part_base + blockIdx.x], acc);
+    }
+}
+
+// ---- RadiusTopology: count, then fill rows sorted by (d2, id) ---------------------------------
+template <typename T, bool FILL>
+__global__ __launch_bounds__(kThreads) void radius_kernel(SearchArgs<T> a, T r, int32_t* __restrict__ counts,
+                                                          const int64_t* __restrict__ offsets,
+                                                          int32_t* __restrict__ idx_out, T* __restrict__ d2_tmp) {
+    const Grid<T> g = *a.grid;
+    const T r2 = r * r; // compared as d2 <= r*r, inclusive (inrange, src/topology.jl:93-94)
+    for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < a.n; slot += gridDim.x * blockDim.x) {
+        const Pt<T> q = a.snap[slot];
+        const int32_t id = w_to_id(q.w);
+        const int cx = cell_coord(g, q.x, 0), cy = cell_coord(g, q.y, 1), cz = cell_coord(g, q.z, 2);
+        const int z0 = cz - 1 < 0 ? 0 : cz - 1, z1 = cz + 1 > g.n[2] - 1 ? g.n[2] - 1 : cz + 1;
+        const int y0 = cy - 1 < 0 ? 0 : cy - 1, y1 = cy + 1 > g.n[1] - 1 ? g.n[1] - 1 : cy + 1;
+        const int x0 = cx - 1 < 0 ? 0 : cx - 1, x1 = cx + 1 > g.n[0] - 1 ? g.n[0] - 1 : cx + 1;
+        int64_t base = FILL ? offsets[id] : 0;
+        int64_t cap = FILL ? offsets[id + 1] - base : 0;
+        int32_t m = 0;
+        for (int z = z0; z <= z1; ++z)
+            for (int y = y0; y <= y1; ++y) {
+                const int row = (z * g.n[1] + y) * g.n[0];
+                const int ps = a.cell_start[row + x0], pe = a.cell_start[row + x1 + 1];
+                for (int p = ps; p < pe; ++p) {
+                    const Pt<T> c = a.snap[p];
+                    const int32_t cid = w_to_id(c.w);
+                    if (cid == id) continue; // filter(!=(i), n), src/topology.jl:96
+                    const T d = dist2<T>(q.x, q.y, q.z, c.x, c.y, c.z);
+                    if (!(d <= r2)) continue;
+                    if (FILL) {
+                        if (m >= cap) continue;
+                        int64_t pos = m;
+                        while (pos > 0 && lex_lt(d, cid, d2_tmp[base + pos - 1], idx_out[base + pos - 1])) {
+                            d2_tmp[base + pos] = d2_tmp[base + pos - 1];
+                            idx_out[base + pos] = idx_out[base + pos - 1];
+                            --pos;
+                        }
+                        d2_tmp[base + pos] = d;
+                        idx_out[base + pos] = cid;
+                    }
+                    ++m;
+                }
+            }
+        if (!FILL) counts[id] = m;
+    }
+}
+
+static inline int blocks_for(int64_t n, int cap) {
+    int64_t b = (n + kThreads - 1) / kThreads;
+    if (b < 1) b = 1;
+    return (int)(b > cap ? cap : b);
+}
+
+template <typename T> int launch_generic_topology(wtp_ctx* ctx, SearchArgs<T>& a, bool all) {
+    const int nb = blocks_for(a.n, all ? 65536 : 1024);
+    hipLaunchKernelGGL((generic_kernel<T, 0>), dim3(nb), dim3(kThreads), 0, ctx->stream, a, a.fb_list,
+                       a.fb_count, all ? 1 : 0, 0);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
+// Partials layout: [0, n_partials - kGenericPartials) belong to the brick kernel, the tail to
+// this one.
+
+template <typename T> int launch_generic_sweep(wtp_ctx* ctx, SearchArgs<T>& a, bool all) {
+    const int nb = blocks_for(a.n, all ? kGenericPartials : 1024);
+    const int part_base = a.n_partials - kGenericPartials;
+    // blocks beyond nb never run: their partial slots are cleared by the caller's memset
+    hipLaunchKernelGGL((generic_kernel<T, 1>), dim3(nb), dim3(kThreads), 0, ctx->stream, a, a.fb_list,
+                       a.fb_count, all ? 1 : 0, part_base);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
+template <typename T>
+int launch_radius_count(wtp_ctx* ctx, SearchArgs<T>& a, T r, int32_t* d_counts) {
+    hipLaunchKernelGGL((radius_kernel<T, false>), dim3(blocks_for(a.n, 65536)), dim3(kThreads), 0, ctx->stream,
+                       a, r, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (T*)nullptr);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
+template <typename T>
+int launch_radius_fill(wtp_ctx* ctx, SearchArgs<T>& a, T r, const int64_t* d_offsets, int32_t* d_idx) {
+    hipLaunchKernelGGL((radius_kernel<T, true>), dim3(blocks_for(a.n, 65536)), dim3(kThreads), 0, ctx->stream,
+                       a, r, (int32_t*)nullptr, d_offsets, d_idx, (T*)ctx->scratch.p);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
+#define INST(T)                                                                              \
+    template int launch_generic_topology<T>(wtp_ctx*, SearchArgs<T>&, bool);                 \
+    template int launch_generic_sweep<T>(wtp_ctx*, SearchArgs<T>&, bool);                    \
+    template int launch_radius_count<T>(wtp_ctx*, SearchArgs<T>&, T, int32_t*);              \
+    template int launch_radius_fill<T>(wtp_ctx*, SearchArgs<T>&, T, const int64_t*, int32_t*);
+INST(float)
+INST(double)
+#undef INST
+
+} // namespace wtp

@@ -1,0 +1,509 @@
+// wtp_hash.hip — counting-sort spatial hash over packed {x,y,z,id} points (gfx950).
+//
+// Replaces the kd-tree build of the reference (KDTree(coords), src/repel.jl:218,252; the
+// KNearestSearch constructor behind src/topology.jl:80).  Passes (algorithmic bytes per point
+// in brackets, fp32):
+//   bbox        read Pt                                   [16]  (fused into setup on rebuilds)
+//   cell_rank   read Pt, atomic count, write cell+rank    [16 + 8]
+//   scan        exclusive scan of per-cell counts         [~1]
+//   scatter     read Pt + cell/rank, write sorted Pt      [16 + 8 + 16]
+//   canon       per-cell order by id (deterministic runs) [in L2]
+// All sizes that depend on the data (cells, bricks) live in the device-resident Grid, so a
+// rebuild needs no host round trip.
+#include "wtp_device.hpp"
+
+namespace wtp {
+
+static constexpr int kThreads = 256;
+
+template <typename T>
+__global__ void load_points_kernel(const T* __restrict__ xyz, Pt<T>* __restrict__ out, int64_t n, int dim) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        Pt<T> p;
+        p.x = xyz[i * dim + 0];
+        p.y = xyz[i * dim + 1];
+        p.z = dim == 3 ? xyz[i * dim + 2] : (T)0;
+        p.w = id_to_w((T)0, (int32_t)i);
+        out[i] = p;
+    }
+}
+
+template <typename T>
+__global__ void bbox_kernel(const Pt<T>* __restrict__ pts, int64_t n, T* __restrict__ part) {
+    __shared__ T sm[6][kThreads / 64];
+    T mn[3] = {Lim<T>::inf(), Lim<T>::inf(), Lim<T>::inf()};
+    T mx[3] = {-Lim<T>::inf(), -Lim<T>::inf(), -Lim<T>::inf()};
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        Pt<T> p = pts[i];
+        mn[0] = p.x < mn[0] ? p.x : mn[0];
+        mx[0] = p.x > mx[0] ? p.x : mx[0];
+        mn[1] = p.y < mn[1] ? p.y : mn[1];
+        mx[1] = p.y > mx[1] ? p.y : mx[1];
+        mn[2] = p.z < mn[2] ? p.z : mn[2];
+        mx[2] = p.z > mx[2] ? p.z : mx[2];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        for (int d = 32; d >= 1; d >>= 1) {
+            T o = __shfl_down(mn[a], d, 64);
+            mn[a] = o < mn[a] ? o : mn[a];
+            o = __shfl_down(mx[a], d, 64);
+            mx[a] = o > mx[a] ? o : mx[a];
+        }
+    }
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        for (int a = 0; a < 3; ++a) {
+            sm[a][wave] = mn[a];
+            sm[3 + a][wave] = mx[a];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int a = 0; a < 3; ++a) {
+            T lo = sm[a][0], hi = sm[3 + a][0];
+            for (int w = 1; w < kThreads / 64; ++w) {
+                lo = sm[a][w] < lo ? sm[a][w] : lo;
+                hi = sm[3 + a][w] > hi ? sm[3 + a][w] : hi;
+            }
+            part[blockIdx.x * 6 + a] = lo;
+            part[blockIdx.x * 6 + 3 + a] = hi;
+        }
+    }
+}
+
+// One thread: final bbox reduce + grid parameters.  rho_k = target points per cell.
+template <typename T>
+__global__ void grid_setup_kernel(const T* __restrict__ part, int nparts, Grid<T>* __restrict__ g,
+                                  int64_t npts, int dim, double rho_k, double radius, int cell_cap) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double mn[3], mx[3];
+    for (int a = 0; a < 3; ++a) {
+        T lo = part[a], hi = part[3 + a];
+        for (int b = 1; b < nparts; ++b) {
+            lo = part[b * 6 + a] < lo ? part[b * 6 + a] : lo;
+            hi = part[b * 6 + 3 + a] > hi ? part[b * 6 + 3 + a] : hi;
+        }
+        mn[a] = (double)lo;
+        mx[a] = (double)hi;
+    }
+    double ext[3], emax = 0;
+    for (int a = 0; a < 3; ++a) {
+        ext[a] = a < dim ? mx[a] - mn[a] : 0.0;
+        if (!(ext[a] >= 0)) ext[a] = 0; // NaN guard
+        emax = ext[a] > emax ? ext[a] : emax;
+    }
+    double c;
+    if (emax <= 0) {
+        c = 1.0;
+    } else {
+        double vol = 1.0;
+        for (int a = 0; a < dim; ++a) vol *= (ext[a] > emax * 1e-6 ? ext[a] : emax * 1e-6);
+        c = pow(rho_k * vol / (double)npts, 1.0 / (double)dim);
+        if (radius > 0) {
+            double cr = radius * (1.0 + 1.0 / 64.0); // c - margin >= radius
+            double cc = pow(2.0 * vol / (double)npts, 1.0 / (double)dim);
+            c = cr > cc ? cr : cc;
+        }
+        if (!(c > 0)) c = emax;
+    }
+    int nn[3];
+    for (int it = 0; it < 400; ++it) {
+        double cells = 1;
+        bool ok = true;
+        for (int a = 0; a < 3; ++a) {
+            double f = a < dim ? floor(ext[a] / c) + 1.0 : 1.0;
+            if (f > (double)kMaxAxisCells) ok = false;
+            nn[a] = f > (double)kMaxAxisCells ? kMaxAxisCells : (int)f;
+            cells *= (double)nn[a];
+        }
+        if (ok && cells <= (double)cell_cap) break;
+        c *= 1.08;
+    }
+    // round the cell edge to T once; every kernel uses these exact values
+    T cT = (T)c;
+    g->c = cT;
+    g->inv_c = (T)1 / cT;
+    g->margin = cT * (T)(1.0 / 256.0);
+    int64_t cells = 1;
+    for (int a = 0; a < 3; ++a) {
+        g->org[a] = (T)mn[a];
+        g->n[a] = nn[a];
+        cells *= nn[a];
+    }
+    g->ncells = (int32_t)cells;
+    g->nb[0] = (nn[0] + BX - 1) / BX;
+    g->nb[1] = (nn[1] + BY - 1) / BY;
+    g->nb[2] = (nn[2] + BZ - 1) / BZ;
+    g->nbricks = g->nb[0] * g->nb[1] * g->nb[2];
+    g->dim = dim;
+    g->npts = (int32_t)npts;
+}
+
+template <typename T>
+__global__ void cell_rank_kernel(const Pt<T>* __restrict__ pts, int64_t n, const Grid<T>* __restrict__ gp,
+                                 int32_t* __restrict__ cell_cnt, int2* __restrict__ cell_rank) {
+    const Grid<T> g = *gp;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        Pt<T> p = pts[i];
+        int cx = cell_coord(g, p.x, 0), cy = cell_coord(g, p.y, 1), cz = cell_coord(g, p.z, 2);
+        int cell = (cz * g.n[1] + cy) * g.n[0] + cx;
+        int r = atomicAdd(&cell_cnt[cell], 1);
+        cell_rank[i] = make_int2(cell, r);
+    }
+}
+
+// ---- exclusive scan of cell counts (1024 cells per block) ------------------------------------
+static constexpr int kScanItems = 4;
+static constexpr int kScanTile = kThreads * kScanItems;
+
+__device__ inline int wave_incl_scan(int v) {
+    int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// returns exclusive prefix of v within the block and the block total via *total
+__device__ inline int block_excl_scan(int v, int* total, int* sm /* [kThreads/64 + 1] */) {
+    int incl = wave_incl_scan(v);
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 63) sm[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int w = 0; w < kThreads / 64; ++w) {
+            int t = sm[w];
+            sm[w] = run;
+            run += t;
+        }
+        sm[kThreads / 64] = run;
+    }
+    __syncthreads();
+    int res = incl - v + sm[wave];
+    *total = sm[kThreads / 64];
+    __syncthreads();
+    return res;
+}
+
+template <typename T>
+__global__ void scan_reduce_kernel(const int32_t* __restrict__ cnt, const Grid<T>* __restrict__ gp,
+                                   int32_t* __restrict__ block_sums) {
+    __shared__ int sm[kThreads / 64 + 1];
+    int ncells = gp->ncells;
+    int base = blockIdx.x * kScanTile;
+    if (base >= ncells) return;
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) {
+        int idx = base + j * kThreads + threadIdx.x;
+        s += idx < ncells ? cnt[idx] : 0;
+    }
+    int total;
+    block_excl_scan(s, &total, sm);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+template <typename T>
+__global__ void scan_top_kernel(int32_t* __restrict__ block_sums, const Grid<T>* __restrict__ gp) {
+    __shared__ int sm[kThreads / 64 + 1];
+    int nblocks = (gp->ncells + kScanTile - 1) / kScanTile;
+    int carry = 0;
+    for (int base = 0; base < nblocks; base += kThreads) {
+        int idx = base + threadIdx.x;
+        int v = idx < nblocks ? block_sums[idx] : 0;
+        int total;
+        int ex = block_excl_scan(v, &total, sm);
+        if (idx < nblocks) block_sums[idx] = carry + ex;
+        carry += total;
+    }
+}
+
+template <typename T>
+__global__ void scan_apply_kernel(const int32_t* __restrict__ cnt, const int32_t* __restrict__ block_sums,
+                                  const Grid<T>* __restrict__ gp, int32_t* __restrict__ cell_start) {
+    __shared__ int sm[kThreads / 64 + 1];
+    int ncells = gp->ncells;
+    int base = blockIdx.x * kScanTile;
+    if (base >= ncells) return;
+    // thread t owns items base + t*kScanItems .. +kScanItems-1 (contiguous per thread)
+    int v[kScanItems];
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) {
+        int idx = base + threadIdx.x * kScanItems + j;
+        v[j] = idx < ncells ? cnt[idx] : 0;
+        s += v[j];
+    }
+    int total;
+    int ex = block_excl_scan(s, &total, sm) + block_sums[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) {
+        int idx = base + threadIdx.x * kScanItems + j;
+        if (idx < ncells) cell_start[idx] = ex;
+        ex += v[j];
+        if (idx == ncells - 1) cell_start[ncells] = ex;
+    }
+}
+
+template <typename T>
+__global__ void scatter_kernel(const Pt<T>* __restrict__ pts, int64_t n, const int2* __restrict__ cell_rank,
+                               const int32_t* __restrict__ cell_start, Pt<T>* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        int2 cr = cell_rank[i];
+        out[cell_start[cr.x] + cr.y] = pts[i];
+    }
+}
+
+// Within-cell order by id: the atomic ranks above depend on arrival order; this makes the
+// sorted array (and every downstream sum) a pure function of the input.  Cells larger than
+// kCanonMax keep arrival order (results stay exact; only fp summation order may vary).
+static constexpr int kCanonMax = 96;
+
+template <typename T>
+__global__ void canon_kernel(Pt<T>* __restrict__ pts, const int32_t* __restrict__ cell_start,
+                             const Grid<T>* __restrict__ gp) {
+    int ncells = gp->ncells;
+    int cell = blockIdx.x * blockDim.x + threadIdx.x;
+    int stride = gridDim.x * blockDim.x;
+    for (; cell < ncells; cell += stride) {
+        int s = cell_start[cell], e = cell_start[cell + 1];
+        int m = e - s;
+        if (m < 2 || m > kCanonMax) continue;
+        for (int i = 1; i < m; ++i) {
+            Pt<T> key = pts[s + i];
+            int kid = w_to_id(key.w);
+            int j = i - 1;
+            while (j >= 0 && w_to_id(pts[s + j].w) > kid) {
+                pts[s + j + 1] = pts[s + j];
+                --j;
+            }
+            pts[s + j + 1] = key;
+        }
+    }
+}
+
+static inline int grid_for(int64_t n, int threads, int cap_blocks) {
+    int64_t b = (n + threads - 1) / threads;
+    if (b < 1) b = 1;
+    return (int)(b > cap_blocks ? cap_blocks : b);
+}
+
+template <typename T>
+int load_points(wtp_ctx* ctx, const T* d_xyz, Pt<T>* out, int64_t n, int dim) {
+    hipLaunchKernelGGL(load_points_kernel<T>, dim3(grid_for(n, kThreads, 8192)), dim3(kThreads), 0,
+                       ctx->stream, d_xyz, out, n, dim);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
+static int cell_capacity(const wtp_ctx* ctx, int64_t n, int k) {
+    double rho = ctx->rho * (k > 0 ? (double)k / 21.0 : 1.0);
+    if (rho < 1.0) rho = 1.0;
+    double cap = (double)n / rho * 1.6 + 4096.0;
+    if (cap > 1.5e9) cap = 1.5e9;
+    return (int)cap;
+}
+
+template <typename T>
+int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, int k, double radius) {
+    const int cap = cell_capacity(ctx, n, radius > 0 ? 6 : k);
+    int rc;
+    if ((rc = ensure(ctx, ctx->grid, sizeof(Grid<double>)))) return rc;
+    const int nbb = grid_for(n, kThreads, 1024);
+    if ((rc = ensure(ctx, ctx->bbox_part, sizeof(double) * 6 * 1024))) return rc;
+    if ((rc = ensure(ctx, ctx->cell_cnt, sizeof(int32_t) * (size_t)(cap + 1)))) return rc;
+    if ((rc = ensure(ctx, ctx->cell_start, sizeof(int32_t) * (size_t)(cap + 2)))) return rc;
+    if ((rc = ensure(ctx, ctx->cell_of, sizeof(int2) * (size_t)n))) return rc;
+    const int nscan = (cap + kScanTile - 1) / kScanTile;
+    if ((rc = ensure(ctx, ctx->scan_tmp, sizeof(int32_t) * (size_t)(nscan + 1)))) return rc;
+
+    Grid<T>* g = (Grid<T>*)ctx->grid.p;
+    T* part = (T*)ctx->bbox_part.p;
+    int32_t* cnt = (int32_t*)ctx->cell_cnt.p;
+    int32_t* start = (int32_t*)ctx->cell_start.p;
+    int2* cr = (int2*)ctx->cell_of.p;
+    int32_t* bs = (int32_t*)ctx->scan_tmp.p;
+    hipStream_t st = ctx->stream;
+
+    // target occupancy: c = 1.17 r_k  (r_k = k-th neighbour distance at uniform density)
+    double rho_k = (dim == 3 ? 0.381 : 0.436) * (double)(k > 0 ? k : 21) * (ctx->rho / 8.0);
+    if (rho_k < 1.0) rho_k = 1.0;
+
+    WTP_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)(cap + 1), st));
+    hipLaunchKernelGGL(bbox_kernel<T>, dim3(nbb), dim3(kThreads), 0, st, in, n, part);
+    hipLaunchKernelGGL(grid_setup_kernel<T>, dim3(1), dim3(64), 0, st, part, nbb, g, n, dim, rho_k, radius, cap);
+    const int nb = grid_for(n, kThreads, 16384);
+    hipLaunchKernelGGL(cell_rank_kernel<T>, dim3(nb), dim3(kThreads), 0, st, in, n, g, cnt, cr);
+    hipLaunchKernelGGL(scan_reduce_kernel<T>, dim3(nscan), dim3(kThreads), 0, st, cnt, g, bs);
+    hipLaunchKernelGGL(scan_top_kernel<T>, dim3(1), dim3(kThreads), 0, st, bs, g);
+    hipLaunchKernelGGL(scan_apply_kernel<T>, dim3(nscan), dim3(kThreads), 0, st, cnt, bs, g, start);
+    hipLaunchKernelGGL(scatter_kernel<T>, dim3(nb), dim3(kThreads), 0, st, in, n, cr, start, out);
+    hipLaunchKernelGGL(canon_kernel<T>, dim3(grid_for(cap, kThreads, 8192)), dim3(kThreads), 0, st, out, start, g);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
+// ---- small utility kernels -----------------------------------------------------------------
+template <typename T>
+__global__ void unpermute_kernel(const Pt<T>* __restrict__ pts, int64_t n, int64_t n_fixed, int dim,
+                                 T* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        Pt<T> p = pts[i];
+        int64_t id = w_to_id(p.w);
+        if (id < n_fixed) continue;
+        T* o = out + (id - n_fixed) * dim;
+        o[0] = p.x;
+        o[1] = p.y;
+        if (dim == 3) o[2] = p.z;
+    }
+}
+
+template <typename T>
+__global__ void unpermute_pd_kernel(const Pt<T>* __restrict__ pts, int64_t n, int64_t n_fixed,
+                                    const T* __restrict__ forces, const T* __restrict__ nn_dist,
+                                    const int32_t* __restrict__ nn_id, T* __restrict__ fo,
+                                    T* __restrict__ no, int32_t* __restrict__ io) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        int64_t id = w_to_id(pts[i].w);
+        if (id < n_fixed) continue;
+        int64_t o = id - n_fixed;
+        if (fo) fo[o] = forces[i];
+        if (no) no[o] = nn_dist[i];
+        if (io) io[o] = nn_id[i];
+    }
+}
+
+template <typename T>
+__global__ void set_point_kernel(Pt<T>* __restrict__ pts, int64_t n, int32_t id, int dim, const T* __restrict__ v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        if (w_to_id(pts[i].w) == id) {
+            pts[i].x = v[0];
+            pts[i].y = v[1];
+            pts[i].z = dim == 3 ? v[2] : (T)0;
+        }
+    }
+}
+
+template <typename T>
+int launch_unpermute(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int64_t n_fixed, int dim, T* d_out) {
+    hipLaunchKernelGGL(unpermute_kernel<T>, dim3(grid_for(n, kThreads, 8192)), dim3(kThreads), 0,
+                       ctx->stream, pts, n, n_fixed, dim, d_out);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
+template <typename T>
+int launch_unpermute_point_data(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int64_t n_fixed,
+                                const T* forces, const T* nn_dist, const int32_t* nn_id, T* fo, T* no,
+                                int32_t* io) {
+    hipLaunchKernelGGL(unpermute_pd_kernel<T>, dim3(grid_for(n, kThreads, 8192)), dim3(kThreads), 0,
+                       ctx->stream, pts, n, n_fixed, forces, nn_dist, nn_id, fo, no, io);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
+template <typename T>
+int launch_set_point(wtp_ctx* ctx, Pt<T>* pts, int64_t n, int32_t id, int dim, const T* d_v) {
+    hipLaunchKernelGGL(set_point_kernel<T>, dim3(grid_for(n, kThreads, 8192)), dim3(kThreads), 0,
+                       ctx->stream, pts, n, id, dim, d_v);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
+// ---- synthetic inputs: splitmix64(seed*2^40 + 3*i + axis) >> 40 * 2^-24 ------
+__device__ inline uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+template <typename T>
+__global__ void gen_uniform_kernel(uint64_t seed, int64_t first, int64_t n, int dim, T* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride)
+        for (int a = 0; a < dim; ++a) {
+            uint64_t h = splitmix64((seed << 40) + 3ull * (uint64_t)(first + i) + (uint64_t)a);
+            out[i * dim + a] = (T)((float)(h >> 40) * (1.0f / 16777216.0f));
+        }
+}
+
+template <typename T>
+int launch_gen_uniform(wtp_ctx* ctx, uint64_t seed, int64_t first, int64_t n, int dim, T* d_out) {
+    hipLaunchKernelGGL(gen_uniform_kernel<T>, dim3(grid_for(n, kThreads, 8192)), dim3(kThreads), 0,
+                       ctx->stream, seed, first, n, dim, d_out);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
+// ---- final reduction of per-block partials (fixed order => deterministic) --------------------
+__global__ void reduce_partials_kernel(const Partial* __restrict__ parts, int n_parts,
+                                       const int32_t* __restrict__ fb_count, wtp_step_stats* __restrict__ out) {
+    __shared__ Acc sm[kThreads / 64];
+    Acc acc = acc_empty();
+    for (int i = threadIdx.x; i < n_parts; i += blockDim.x) {
+        if (parts[i].n_move == 0) continue; // slot of a block that saw no movable point
+        Acc o;
+        o.max_force = parts[i].max_force;
+        o.sum_u = parts[i].sum_u;
+        o.sum_u2 = parts[i].sum_u2;
+        o.argmin_r = parts[i].argmin_r;
+        o.argmin_i = parts[i].argmin_i;
+        o.argmin_j = parts[i].argmin_j;
+        o.n_move = parts[i].n_move;
+        acc_merge(acc, o);
+    }
+    acc_block_reduce(acc, sm);
+    if (threadIdx.x == 0) {
+        out->max_force = acc.max_force;
+        out->sum_u = acc.sum_u;
+        out->sum_u2 = acc.sum_u2;
+        out->n_move = acc.n_move;
+        out->argmin_i = acc.argmin_i;
+        out->argmin_j = acc.argmin_j;
+        out->argmin_r = acc.argmin_r;
+        out->n_fallback = fb_count ? *fb_count : 0;
+    }
+}
+
+int launch_reduce_partials(wtp_ctx* ctx, const Partial* parts, int n_parts, const int32_t* fb_count,
+                           wtp_step_stats* d_slot) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, parts, n_parts,
+                       fb_count, d_slot);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
+// explicit instantiations
+#define INST(T)                                                                                         \
+    template int load_points<T>(wtp_ctx*, const T*, Pt<T>*, int64_t, int);                              \
+    template int build_hash<T>(wtp_ctx*, const Pt<T>*, Pt<T>*, int64_t, int, int, double);              \
+    template int launch_unpermute<T>(wtp_ctx*, const Pt<T>*, int64_t, int64_t, int, T*);                \
+    template int launch_unpermute_point_data<T>(wtp_ctx*, const Pt<T>*, int64_t, int64_t, const T*,    \
+                                                const T*, const int32_t*, T*, T*, int32_t*);            \
+    template int launch_set_point<T>(wtp_ctx*, Pt<T>*, int64_t, int32_t, int, const T*);                \
+    template int launch_gen_uniform<T>(wtp_ctx*, uint64_t, int64_t, int64_t, int, T*);
+INST(float)
+INST(double)
+#undef INST
+
+} // namespace wtp

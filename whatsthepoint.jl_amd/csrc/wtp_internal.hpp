@@ -1,0 +1,219 @@
+// wtp_internal.hpp — shared types of libwtp (gfx950 only; no portability layer).
+//
+// Data layout in HBM:
+//   Pt<T>      one point = {x, y, z, bits(id)} : float4 (16 B) / double4 (32 B).  One 16-B
+//              (or 2x16-B) coalesced access moves a whole point; the id rides along so the
+//              counting sort permutes nothing else.
+//   cell_start int32[ncells+1]  exclusive scan of per-cell counts (row-major cz,cy,cx).
+//   Points of one cell are contiguous, cells of one x-row are contiguous.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/wtp.h"
+
+namespace wtp {
+
+// ---- point record ---------------------------------------------------------------------------
+template <typename T> struct PtOf;
+template <> struct PtOf<float> { using type = float4; };
+template <> struct PtOf<double> { using type = double4; };
+template <typename T> using Pt = typename PtOf<T>::type;
+
+__host__ __device__ inline float id_to_w(float, int32_t id) { return __builtin_bit_cast(float, id); }
+__host__ __device__ inline double id_to_w(double, int32_t id) {
+    return __builtin_bit_cast(double, (int64_t)id);
+}
+__host__ __device__ inline int32_t w_to_id(float w) { return __builtin_bit_cast(int32_t, w); }
+__host__ __device__ inline int32_t w_to_id(double w) {
+    return (int32_t)__builtin_bit_cast(int64_t, w);
+}
+
+// ---- uniform grid (device resident; written by grid_setup_kernel) ------------------------------
+// Cell of coordinate v on axis a: clamp((int)floor((v - org[a]) * inv_c), 0, n[a]-1).
+// Points outside the box (repel has no wall inside the sweep) pile into the edge cells; the
+// exactness radius treats those cells as unbounded outward.
+template <typename T> struct Grid {
+    T org[3];
+    T c;      // cell edge
+    T inv_c;  // 1/c
+    T margin; // c * 2^-8: covers the rounding of the cell map (n[a] <= 4096 enforced)
+    int32_t n[3];
+    int32_t ncells;
+    int32_t nb[3];   // bricks per axis
+    int32_t nbricks;
+    int32_t dim;
+    int32_t npts;
+};
+
+constexpr int kMaxAxisCells = 4096;
+
+// Brick geometry of the fast path: one workgroup sweeps BX x BY x BZ cells, staging the
+// (BX+2)(BY+2)(BZ+2) halo in LDS.
+constexpr int BX = 4, BY = 4, BZ = 4;
+constexpr int HX = BX + 2, HY = BY + 2, HZ = BZ + 2;
+constexpr int HCELLS = HX * HY * HZ;
+constexpr int kBrickThreads = 256;
+// partial-reduction slots: [0, brick_partials()) brick kernel blocks, then kGenericPartials
+constexpr int kGenericPartials = 4096;
+int brick_partials();
+constexpr int kGenericKMax = 128; // largest k the library accepts (generic kernel's list)
+
+// ---- per-block partial reductions of one sweep -------------------------------------------------
+struct Partial {
+    double max_force;
+    double sum_u;
+    double sum_u2;
+    double argmin_r;   // +inf when empty
+    int64_t argmin_i;  // snapshot-global id of the movable point (ties: lowest id)
+    int64_t argmin_j;
+    int64_t n_move;
+};
+
+struct ForceParams {
+    int32_t kind;
+    double beta, u0, gamma;
+};
+
+// ---- kernel parameter blocks -------------------------------------------------------------------
+template <typename T> struct SearchArgs {
+    const Grid<T>* grid;
+    const Pt<T>* snap;         // sorted snapshot (search structure)
+    const int32_t* cell_start; // ncells+1
+    const Pt<T>* query;        // query positions, slot-aligned with snap (== snap when fresh)
+    int32_t n;
+    int32_t k;                 // neighbours wanted (relax: kk incl. self slot)
+    int32_t include_self;      // topology: 1 = raw search result, 0 = self removed by index
+    // topology outputs (row = original id)
+    int32_t* idx_out;
+    T* dist_out;
+    // relax
+    Pt<T>* out;                // new positions, slot order
+    T* forces;                 // slot order
+    T* nn_dist;
+    int32_t* nn_id;
+    const T* spacing_pp;       // per-point spacing by original id, or nullptr
+    T spacing_const;
+    T alpha_lo, alpha_max;
+    T beta, u0, gamma;
+    int32_t force_kind;
+    int32_t n_fixed;
+    Partial* partials;         // [n_partials]
+    int32_t n_partials;
+    // fallback work list
+    int32_t* fb_list;
+    int32_t* fb_count;
+    // tunables
+    T gamma_cap;               // initial filter radius cap, in cell edges
+};
+
+// ---- device buffer with capacity -----------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct RelaxState {
+    bool active = false;
+    int64_t n = 0, n_fixed = 0;
+    int dim = 3, dtype = 0, k = 0;
+    int spacing_kind = 0;
+    double spacing_const = 0, alpha_lo = 0, alpha_max = 0;
+    ForceParams force{};
+    int bufS = -1, bufP = -1, bufOld = -1; // indices into pts[3]
+    bool have_tree = false;
+    bool can_revert = false;
+    bool have_point_data = false;
+};
+
+} // namespace wtp
+
+struct wtp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int sm_count = 256;
+    // tunables (env WTP_RHO / WTP_GAMMA_CAP / WTP_FORCE_GENERIC)
+    double rho = 8.0;
+    double gamma_cap = 1.08;
+    int force_generic = 0;
+    // pooled device buffers
+    wtp::DevBuf pts[3];        // Pt arrays
+    wtp::DevBuf raw_in;        // AoS staging of host input
+    wtp::DevBuf cell_of, rank_of, cell_cnt, cell_start, scan_tmp;
+    wtp::DevBuf grid, bbox_part;
+    wtp::DevBuf idx_out, dist_out, counts_out;
+    wtp::DevBuf forces, nn_dist, nn_id, spacing_pp;
+    wtp::DevBuf partials, stats, fb_list, fb_count;
+    wtp::DevBuf scratch;       // misc (relax_get staging, radius rows)
+    void* host_pinned = nullptr;
+    size_t host_pinned_cap = 0;
+    // radius two-phase state
+    int64_t rad_n = 0;
+    int rad_dim = 0, rad_dtype = 0;
+    double rad_r = 0;
+    bool rad_valid = false;
+    wtp::RelaxState relax;
+    // timers
+    bool timing = true;
+    double t_hash = 0, t_sweep = 0, t_other = 0;
+    int64_t n_sweep_launches = 0;
+    std::vector<hipEvent_t> ev_pool;
+    struct Span { int a, b, kind; };
+    std::vector<Span> spans;
+    int ev_used = 0;
+};
+
+namespace wtp {
+
+// error plumbing
+int fail(wtp_ctx* ctx, int code, const std::string& msg);
+#define WTP_HIP(ctx, call)                                                                    \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return ::wtp::fail(ctx, e_ == hipErrorOutOfMemory ? WTP_ERR_OOM : WTP_ERR_HIP,    \
+                               std::string(#call) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+int ensure(wtp_ctx* ctx, DevBuf& b, size_t bytes);
+
+// timing spans: kind 0 hash, 1 sweep, 2 other
+int span_begin(wtp_ctx* ctx, int kind);
+void span_end(wtp_ctx* ctx, int span);
+void spans_collect(wtp_ctx* ctx);
+
+// ---- launch wrappers (implemented per translation unit) ----------------------------------------
+// hash build: from Pt array `in` (n points) produce sorted `out`, cell_start and the grid.
+// radius > 0 forces cell edge >= radius (RadiusTopology); k scales the target occupancy.
+template <typename T>
+int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, int k, double radius);
+
+template <typename T>
+int load_points(wtp_ctx* ctx, const T* d_xyz, Pt<T>* out, int64_t n, int dim);
+
+template <typename T> int launch_topology(wtp_ctx* ctx, SearchArgs<T>& a);
+template <typename T> int launch_sweep(wtp_ctx* ctx, SearchArgs<T>& a, bool fresh);
+template <typename T> int launch_generic_topology(wtp_ctx* ctx, SearchArgs<T>& a, bool all);
+template <typename T> int launch_generic_sweep(wtp_ctx* ctx, SearchArgs<T>& a, bool all);
+template <typename T>
+int launch_radius_count(wtp_ctx* ctx, SearchArgs<T>& a, T r, int32_t* d_counts);
+template <typename T>
+int launch_radius_fill(wtp_ctx* ctx, SearchArgs<T>& a, T r, const int64_t* d_offsets,
+                       int32_t* d_idx);
+int launch_reduce_partials(wtp_ctx* ctx, const Partial* parts, int n_parts, const int32_t* fb_count,
+                           wtp_step_stats* d_stats_slot);
+template <typename T>
+int launch_unpermute(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int64_t n_fixed, int dim, T* d_xyz_out);
+template <typename T>
+int launch_unpermute_point_data(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int64_t n_fixed,
+                                const T* forces, const T* nn_dist, const int32_t* nn_id,
+                                T* forces_o, T* nn_dist_o, int32_t* nn_id_o);
+template <typename T>
+int launch_set_point(wtp_ctx* ctx, Pt<T>* pts, int64_t n, int32_t id, int dim, const T* d_xyz3);
+template <typename T>
+int launch_gen_uniform(wtp_ctx* ctx, uint64_t seed, int64_t first, int64_t n, int dim, T* d_out);
+
+} // namespace wtp

@@ -1,0 +1,215 @@
+"""Thin host wrappers over the C ABI (include/wtp.h): one `Context` per GPU.
+
+Everything here only marshals numpy arrays to libwtp; the algorithms live in csrc/.
+There is deliberately no CPU implementation behind these calls.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _dtype_code(dt) -> int:
+    dt = np.dtype(dt)
+    if dt == np.float32:
+        return L.WTP_F32
+    if dt == np.float64:
+        return L.WTP_F64
+    raise L.WtpArgumentError(f"coordinates must be float32 or float64, got {dt}")
+
+
+def _cloud(xyz):
+    xyz = np.asarray(xyz)
+    if xyz.ndim != 2 or xyz.shape[1] not in (2, 3):
+        raise L.WtpArgumentError("coordinates must have shape (n, 2) or (n, 3)")
+    if xyz.dtype not in (np.float32, np.float64):
+        xyz = xyz.astype(np.float64)
+    return np.ascontiguousarray(xyz)
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Context:
+    """Owns the device buffers, stream and timers of one GPU (wtp_create / wtp_destroy)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = L.load()
+        h = C.c_void_p()
+        dev = (C.c_int * 1)(device)
+        rc = self._lib.wtp_create(dev, 1, C.byref(h))
+        if rc != L.WTP_OK:
+            L.check(None, rc)
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.wtp_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- KNNTopology / KNearestSearch (src/topology.jl:79-84, src/neighbors.jl) ---------
+    def knn(self, xyz, k: int, include_self: bool = False, return_dist: bool = False):
+        xyz = _cloud(xyz)
+        n, dim = xyz.shape
+        if k < 1 or k > n - (0 if include_self else 1):
+            raise L.WtpArgumentError(f"k={k} needs k+1 <= n={n} points")
+        idx = np.empty((n, k), dtype=np.int32)
+        dist = np.empty((n, k), dtype=xyz.dtype) if return_dist else None
+        rc = self._lib.wtp_knn(self._h, _vp(xyz), n, dim, _dtype_code(xyz.dtype), int(k), int(bool(include_self)),
+                               _vp(idx), _vp(dist))
+        L.check(self._h, rc)
+        return (idx, dist) if return_dist else idx
+
+    def knn_dev(self, d_xyz_ptr: int, n: int, dim: int, dtype, k: int, include_self: bool, d_idx_ptr: int,
+                d_dist_ptr: int = 0):
+        rc = self._lib.wtp_knn_dev(self._h, C.c_void_p(d_xyz_ptr), n, dim, _dtype_code(dtype), int(k),
+                                   int(bool(include_self)), C.c_void_p(d_idx_ptr),
+                                   C.c_void_p(d_dist_ptr) if d_dist_ptr else None)
+        L.check(self._h, rc)
+
+    # ---- RadiusTopology / BallSearch (src/topology.jl:91-97) -----------------------------
+    def radius(self, xyz, r: float):
+        """CSR stencils: (offsets int64[n+1], idx int32[nnz]); rows ascending (d2, index)."""
+        xyz = _cloud(xyz)
+        n, dim = xyz.shape
+        counts = np.empty(n, dtype=np.int32)
+        rc = self._lib.wtp_radius_count(self._h, _vp(xyz), n, dim, _dtype_code(xyz.dtype), float(r), _vp(counts))
+        L.check(self._h, rc)
+        offsets = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(counts, out=offsets[1:])
+        idx = np.empty(max(int(offsets[-1]), 1), dtype=np.int32)
+        rc = self._lib.wtp_radius_fill(self._h, _vp(offsets), _vp(idx))
+        L.check(self._h, rc)
+        return offsets, idx[: int(offsets[-1])]
+
+    # ---- repel -------------------------------------------------------------------------------
+    def relax(self, snap, n_fixed: int, spacing, force, k: int, alpha_lo: float, alpha_max: float):
+        return RelaxSession(self, snap, n_fixed, spacing, force, k, alpha_lo, alpha_max)
+
+    # ---- measurement ---------------------------------------------------------------------------
+    def timers(self):
+        out = (C.c_double * 4)()
+        L.check(self._h, self._lib.wtp_timers_get(self._h, out))
+        return dict(hash_ms=out[0], sweep_ms=out[1], other_ms=out[2], sweep_launches=int(out[3]))
+
+    def timers_reset(self):
+        L.check(self._h, self._lib.wtp_timers_reset(self._h))
+
+    def gen_uniform_dev(self, seed: int, first: int, n: int, dim: int, dtype, d_out_ptr: int):
+        rc = self._lib.wtp_gen_uniform_dev(self._h, C.c_uint64(seed), first, n, dim, _dtype_code(dtype),
+                                           C.c_void_p(d_out_ptr))
+        L.check(self._h, rc)
+
+
+def _stats_dict(s: L.StepStats):
+    return dict(max_force=s.max_force, sum_u=s.sum_u, sum_u2=s.sum_u2, n_move=s.n_move, argmin_i=s.argmin_i,
+                argmin_j=s.argmin_j, argmin_r=s.argmin_r, n_fallback=s.n_fallback)
+
+
+class RelaxSession:
+    """Device-resident state of one `_relax!` call (src/repel.jl:202-339): coordinates stay in
+    HBM between sweeps; the host sees three scalars per iteration."""
+
+    def __init__(self, ctx: Context, snap, n_fixed: int, spacing, force, k: int, alpha_lo: float, alpha_max: float):
+        self.ctx = ctx
+        self._lib = ctx._lib
+        snap = _cloud(snap)
+        self.n, self.dim = snap.shape
+        self.dtype = snap.dtype
+        self.n_fixed = int(n_fixed)
+        sd = L.SpacingDesc()
+        self._sp_keep = None
+        if np.isscalar(spacing):
+            sd.kind, sd.constant, sd.per_point = 0, float(spacing), None
+        else:
+            sp = np.ascontiguousarray(spacing, dtype=self.dtype)
+            if sp.shape != (self.n,):
+                raise L.WtpArgumentError("per-point spacing needs one value per snapshot point")
+            self._sp_keep = sp
+            sd.kind, sd.constant, sd.per_point = 1, 0.0, sp.ctypes.data
+        fd = L.ForceDesc(int(force["kind"]), float(force["beta"]), float(force.get("u0", 1.0)),
+                         float(force.get("gamma", 3.0)))
+        rc = self._lib.wtp_relax_init(ctx._h, _vp(snap), self.n, self.n_fixed, self.dim, _dtype_code(self.dtype),
+                                      C.byref(sd), C.byref(fd), int(k), float(alpha_lo), float(alpha_max))
+        L.check(ctx._h, rc)
+        self._open = True
+
+    def step(self, rebuild: bool = True):
+        st = L.StepStats()
+        L.check(self.ctx._h, self._lib.wtp_relax_step(self.ctx._h, int(bool(rebuild)), C.byref(st)))
+        return _stats_dict(st)
+
+    def run(self, n_iters: int, rebuild_every: int = 1):
+        conv = np.zeros(max(n_iters, 1), dtype=np.float64)
+        st = L.StepStats()
+        L.check(self.ctx._h, self._lib.wtp_relax_run(self.ctx._h, int(n_iters), int(rebuild_every), _vp(conv),
+                                                     C.byref(st)))
+        return conv[:n_iters], _stats_dict(st)
+
+    def run_async_free(self, n_iters: int, rebuild_every: int = 1):
+        """n_iters sweeps with no read-back at all (bench inner loop)."""
+        L.check(self.ctx._h, self._lib.wtp_relax_run(self.ctx._h, int(n_iters), int(rebuild_every), None, None))
+
+    def positions(self):
+        out = np.empty((self.n - self.n_fixed, self.dim), dtype=self.dtype)
+        L.check(self.ctx._h, self._lib.wtp_relax_get(self.ctx._h, _vp(out)))
+        return out
+
+    def point_data(self):
+        m = self.n - self.n_fixed
+        forces = np.empty(m, dtype=self.dtype)
+        nn_dist = np.empty(m, dtype=self.dtype)
+        nn_id = np.empty(m, dtype=np.int32)
+        L.check(self.ctx._h, self._lib.wtp_relax_get_point_data(self.ctx._h, _vp(forces), _vp(nn_dist), _vp(nn_id)))
+        return dict(forces=forces, nn_dist=nn_dist, nn_id=nn_id)
+
+    def set_point(self, i: int, xyz):
+        v = np.ascontiguousarray(xyz, dtype=self.dtype).reshape(self.dim)
+        L.check(self.ctx._h, self._lib.wtp_relax_set(self.ctx._h, int(i), _vp(v)))
+
+    def revert(self):
+        L.check(self.ctx._h, self._lib.wtp_relax_revert(self.ctx._h))
+
+    def set_spacing(self, spacing):
+        sp = np.ascontiguousarray(spacing, dtype=self.dtype)
+        if sp.shape != (self.n,):
+            raise L.WtpArgumentError("per-point spacing needs one value per snapshot point")
+        L.check(self.ctx._h, self._lib.wtp_relax_set_spacing(self.ctx._h, _vp(sp)))
+
+    def close(self):
+        if self._open and self.ctx._h:
+            self._lib.wtp_relax_end(self.ctx._h)
+        self._open = False
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+_default_ctx = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None or _default_ctx._h is None:
+        _default_ctx = Context(0)
+    return _default_ctx

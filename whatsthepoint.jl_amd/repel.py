@@ -1,0 +1,151 @@
+"""`repel` — host side of the reference's node repulsion (src/repel.jl:56-95,202-339).
+
+The sweep (k-NN rebuild + force + step + reductions) runs on the GPU through libwtp; this
+module keeps what the reference keeps on the calling thread: defaults, argument checks, the stop
+rules of src/repel.jl:305-334, the kick (:415-433) and the closest-pair trace (:294-296).
+Out of scope here: the `isinside` post-filter (src/repel.jl:90) and the octree
+wall rule (:448-537) — pass `inside=` to filter survivors yourself."""
+from __future__ import annotations
+
+import logging
+import math
+
+import numpy as np
+
+from . import topology as T
+from .cloud import PointCloud, PointVolume
+from .engine import default_context
+from .forces import ClippedSpacingForce, RepelForceModel
+from ._lib import WtpArgumentError
+
+log = logging.getLogger("wtp_amd.repel")
+
+
+def _spacing_values(spacing, pts):
+    if np.isscalar(spacing):
+        return float(spacing), True
+    if callable(spacing):
+        v = spacing(pts)
+        if np.isscalar(v):
+            return float(v), True
+        v = np.asarray(v)
+        if v.size and np.all(v == v.flat[0]):
+            return float(v.flat[0]), True
+        return v.astype(pts.dtype), False
+    v = np.asarray(spacing)
+    return v.astype(pts.dtype), False
+
+
+def relax(p, snap_fixed, spacing, force_model, *, alpha_lo, alpha_max, k=21, max_iters=1000, tol=1e-6,
+          rebuild_every=1, kick_after=0, stall_after=0, cv_target=0.0, trace=None, n_protected=None,
+          rng=None, ctx=None):
+    """_relax! (src/repel.jl:202-339).  p: movable points (n_move x dim); snap_fixed: the static
+    head of the search snapshot (may be empty).  Returns (p_final, conv list)."""
+    if rebuild_every < 1:
+        raise WtpArgumentError("rebuild_every must be ≥ 1")  # src/repel.jl:74
+    ctx = ctx or default_context()
+    p = np.ascontiguousarray(p)
+    n_fixed = len(snap_fixed)
+    snap = np.concatenate([np.asarray(snap_fixed, dtype=p.dtype).reshape(n_fixed, p.shape[1]), p], axis=0)
+    n_move = len(p)
+    n_protected = n_fixed if n_protected is None else n_protected
+    sp, const = _spacing_values(spacing, snap)
+    spacings = np.full(len(snap), sp, dtype=p.dtype) if const else sp
+    variable = (not const) and callable(spacing)
+    conv = []
+    if n_move == 0 or max_iters < 1:
+        return p, conv
+    rng = rng or np.random.default_rng()
+    kick_state = dict(pair=(0, 0), rs=math.inf, count=0)
+    best_cv, last_impr = math.inf, 0
+    sess = ctx.relax(snap, n_fixed, sp if const else spacings, force_model.desc(), k, alpha_lo, alpha_max)
+    try:
+        i = 1
+        while i <= max_iters:
+            rebuild = (i - 1) % rebuild_every == 0
+            if rebuild and variable and i > 1:
+                # spacings at the current positions (src/repel.jl:251)
+                cur = sess.positions()
+                spacings[n_fixed:] = np.asarray(spacing(cur), dtype=p.dtype)
+                sess.set_spacing(spacings)
+            st = sess.step(rebuild)
+            conv.append(st["max_force"])  # maximum(forces) :293
+            if n_move > 0 and (trace is not None or kick_after > 0):
+                ig, j, r = st["argmin_i"], st["argmin_j"], st["argmin_r"]  # _closest_pair :396-403
+                s_pair = (spacings[ig] + spacings[j]) / 2 if j >= 0 else spacings[ig]
+                pair = dict(r=r, s=float(s_pair), r_over_s=r / float(s_pair), idx_a=min(ig, j), idx_b=max(ig, j))
+                if trace is not None:
+                    trace.append(dict(iteration=i, **pair))
+                if kick_after > 0:
+                    kick_state, kicked = _maybe_kick(sess, pair, kick_state, kick_after, spacings, n_fixed,
+                                                     n_protected, rng)
+                    if kicked:
+                        log.debug("Kicked frozen pair at iteration %d", i)
+            if (stall_after > 0 or cv_target > 0) and n_move > 0:
+                mu = st["sum_u"] / st["n_move"]  # _dnn_cv :374-386
+                cv = math.sqrt(max(st["sum_u2"] / st["n_move"] - mu * mu, 0.0)) / mu
+                if cv_target > 0 and cv <= cv_target:
+                    sess.revert()  # p .= p_old :314
+                    log.info("Node repel stopped in %d iterations: spacing CV target reached", i)
+                    break
+                if stall_after > 0:
+                    if cv < best_cv * (1 - 1.0e-3):
+                        best_cv, last_impr = cv, i
+                    elif i - last_impr >= stall_after:
+                        log.info("Node repel stopped in %d iterations: spacing CV stalled for %d iterations",
+                                 i, stall_after)
+                        break
+            if conv[-1] < tol:
+                log.info("Node repel finished in %d iterations", i)
+                break
+            i += 1
+        if i > max_iters:
+            log.warning("Node repel reached maximum iterations (%d), convergence=%g", max_iters, conv[-1])
+        out = sess.positions()
+    finally:
+        sess.close()
+    return out, conv
+
+
+def _maybe_kick(sess, pair, state, kick_after, spacings, n_fixed, n_protected, rng):
+    """_maybe_kick! (src/repel.jl:415-433), indices 0-based."""
+    frozen = (pair["idx_a"], pair["idx_b"]) == state["pair"] and abs(pair["r_over_s"] - state["rs"]) < 1.0e-8
+    count = state["count"] + 1 if frozen else 1
+    if count < kick_after:
+        return dict(pair=(pair["idx_a"], pair["idx_b"]), rs=pair["r_over_s"], count=count), False
+    a, b = pair["idx_a"], pair["idx_b"]
+    target = a if a >= n_protected else (b if b >= n_protected else (a if a >= n_fixed else b))
+    s = float(spacings[target])
+    cur = sess.positions()
+    d = rng.standard_normal(cur.shape[1])
+    newp = cur[target - n_fixed] + (s / 10) * (d / np.linalg.norm(d))
+    sess.set_point(target - n_fixed, newp.astype(cur.dtype))
+    return dict(pair=(a, b), rs=pair["r_over_s"], count=0), True
+
+
+def repel(cloud: PointCloud, spacing, *, beta=0.2, force_model: RepelForceModel = None, alpha=None,
+          alpha_min=None, k=21, max_iters=1000, tol=1.0e-6, rebuild_every=1, cull_ratio=0.0, kick_after=0,
+          stall_after=50, cv_target=0.0, convergence=None, trace=None, inside=None, ctx=None):
+    """repel(cloud, spacing; kwargs...) — volume points move, boundary points are the fixed wall
+    (src/repel.jl:56-95).  Returns a new cloud with NoTopology."""
+    if rebuild_every < 1:
+        raise WtpArgumentError("rebuild_every must be ≥ 1")
+    force_model = force_model or ClippedSpacingForce(beta)
+    bnd_p = cloud.boundary.points()
+    p = np.array(cloud.volume.points(), copy=True)
+    allp = cloud.points()
+    if alpha is None:
+        sv, const = _spacing_values(spacing, allp)
+        alpha = (sv if const else float(np.min(sv))) / 20  # minimum(spacing.(to(cloud)))/20 :61
+    if alpha_min is None:
+        alpha_min = alpha / 100
+    out, conv = relax(p, bnd_p.astype(p.dtype, copy=False) if len(p) else bnd_p, spacing, force_model,
+                      alpha_lo=alpha_min, alpha_max=alpha, k=k, max_iters=max_iters, tol=tol,
+                      rebuild_every=rebuild_every, kick_after=kick_after, stall_after=stall_after,
+                      cv_target=cv_target, trace=trace, n_protected=len(bnd_p), ctx=ctx)
+    if convergence is not None:
+        convergence.extend(conv)
+    survivors = out if inside is None else out[np.asarray(inside(out), dtype=bool)]
+    if cull_ratio > 0 and len(survivors):
+        raise NotImplementedError("cull_ratio > 0: _near_duplicate_keep_mask is SURVEY.md §8f (next)")
+    return PointCloud(cloud.boundary, PointVolume(survivors), T.NoTopology())
