@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the neighbour/stencil hot path on MI355X.
+
+Metric (BASELINE.json): Mpoints/s per repel iteration (k=21 k-NN + Miotti force), 10 M uniform
+fp32 points per GPU, rebuild_every=1 (hash rebuild + fused sweep + reductions every step), with
+the achieved fraction of the HBM roofline of the dominant kernel next to it.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--points P] [--no-cpu]
+
+One step = one pass of the hot path (src/repel.jl:244-293) over the whole cloud, coordinates
+resident in HBM.  N > 1 is launched by torch.distributed.run, one rank per GPU; the cloud is
+sharded into z-slabs with a one-cell ghost layer exchanged through RCCL every iteration
+(whatsthepoint.jl_amd/sharded.py).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_ALG_SWEEP = 41.0   # algorithmic bytes/point of the fused sweep: 16 in + 12+4+4+4 out (+1 cell table)
+B_ALG_ITER = 91.0    # hash 50 + sweep 41
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
+
+
+def cpu_baseline(points: int, iters: int):
+    """The oracle's kd-tree + OpenMP restatement of the same sweep ("port"), timed on this host."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+
+    import oracle as O
+
+    import wtp_amd
+
+    x = wtp_amd.synth.uniform(points, 3, np.float32)
+    s = float(points) ** (-1.0 / 3.0)
+    t0 = time.perf_counter()
+    O.relax_loop(x, 0, s, 2, 0.2, 1.0, 3.0, 21, s / 2000, s / 20, max_iters=iters, tol=0.0, rebuild_every=1,
+                 stall_after=0)
+    dt = time.perf_counter() - t0
+    return dict(value=points * iters / dt / 1e6, unit="Mpoints/s", cores=O.num_threads(), kind="port",
+                sample=f"{iters} repel iterations on {points} uniform fp32 points (kd-tree + OpenMP oracle, {dt:.1f} s)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=10_000_000, help="points per GPU (weak scaling)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-points", type=int, default=1_000_000)
+    ap.add_argument("--cpu-iters", type=int, default=4)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import wtp_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n_local = args.points
+    n_total = n_local * world
+    k = 21
+    s = float(n_total) ** (-1.0 / 3.0)  # ConstantSpacing N^(-1/3), alpha = s/20, alpha_min = alpha/100
+    force = dict(kind=2, beta=0.2, u0=1.0, gamma=3.0)
+    ctx = wtp_amd.Context(local_rank)
+
+    if world == 1:
+        xyz = torch.empty((n_local, 3), dtype=torch.float32, device="cuda")
+        ctx.gen_uniform_dev(wtp_amd.synth.SEED, 0, n_local, 3, np.float32, xyz.data_ptr())
+        sess = ctx.relax(None, 0, s, force, k, s / 2000, s / 20, device_ptr=(xyz.data_ptr(), n_local, 3, np.float32))
+        del xyz
+
+        def run(iters):
+            sess.run_async_free(iters, 1)
+    else:
+        from whatsthepoint_jl_amd import sharded
+
+        drv = sharded.ShardedRelax(ctx, dist, n_total, s, force, k, s / 2000, s / 20, seed=wtp_amd.synth.SEED)
+
+        def run(iters):
+            drv.run(iters)
+
+    run(args.warmup)
+    ctx.timers_reset()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    tm = ctx.timers()
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = n_total * args.steps / dt / 1e6
+        launches = max(tm["sweep_launches"], 1)
+        sweep_ms = tm["sweep_ms"] / launches
+        pts_per_launch = n_local if world == 1 else drv.points_per_launch()
+        achieved = B_ALG_SWEEP * pts_per_launch / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+        out = {
+            "metric": "Mpoints/sec per repel iter (k=21 KNN+force)",
+            "value": round(value, 3),
+            "unit": "Mpoints/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{n_total} uniform fp32 points in the unit cube, repel sweep k=21, "
+                            f"ClippedSpacingForce(beta=0.2), ConstantSpacing N^(-1/3), rebuild_every=1, "
+                            f"stall_after=0, tol=0 (BASELINE.json configs[2])",
+                "points_per_gpu": n_local,
+                "sharding": "none" if world == 1 else f"{world} z-slabs + one-cell ghost exchange (RCCL)",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "wtp::brick_kernel<1> (fused 27-cell k-NN + repel sweep)",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": None,
+                "avg_launch_ms": round(sweep_ms, 4),
+                "alg_bytes_per_point": B_ALG_SWEEP,
+                "iteration_alg_gbs": round(B_ALG_ITER * n_total / (ms_per_step * 1e-3) / 1e9, 2),
+            },
+            "phase_ms_per_step": {
+                "hash": round(tm["hash_ms"] / args.steps, 4),
+                "sweep": round(tm["sweep_ms"] / args.steps, 4),
+                "fallback_reduce": round(tm["other_ms"] / args.steps, 4),
+            },
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_points, args.cpu_iters)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

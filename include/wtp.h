@@ -135,6 +135,11 @@ int wtp_relax_init(wtp_ctx* ctx, const void* snap_xyz, int64_t n, int64_t n_fixe
                    int dtype, const wtp_spacing_desc* spacing, const wtp_force_desc* force,
                    int k, double alpha_lo, double alpha_max);
 
+/* Same with the snapshot already on the context's GPU (spacing->per_point stays a host array). */
+int wtp_relax_init_dev(wtp_ctx* ctx, const void* d_snap_xyz, int64_t n, int64_t n_fixed, int dim,
+                       int dtype, const wtp_spacing_desc* spacing, const wtp_force_desc* force,
+                       int k, double alpha_lo, double alpha_max);
+
 /* One pass of src/repel.jl:244-293 plus the reductions of :293,374-403.
  * rebuild != 0 refreshes the search snapshot from the current positions first
  * (repel.jl:245-253); rebuild == 0 sweeps against the stale snapshot. */

@@ -1,0 +1,166 @@
+"""Pin the CPU oracle against every known answer the reference's own tests hold for this path
+ — closed-form fixtures, no Julia needed — and against independent exact k-NN
+(scipy cKDTree, numpy brute force).  What stays unpinned (tie order vs NearestNeighbors.jl,
+repelled coordinates) is stated in oracle/wtp_oracle.c."""
+import math
+
+import numpy as np
+import pytest
+
+
+def test_circle_k3_self_first(O):
+    # test/neighbors.jl:34-57: 20 points on the unit circle, k=3 -> {i, i±1}, self first
+    N = 20
+    th = np.linspace(0, 2 * np.pi, N + 1)[:-1]
+    pts = np.stack([np.cos(th), np.sin(th)], 1)
+    idx, dist = O.knn(pts, 3, True, "brute")
+    assert idx.shape == (N, 3)
+    assert (idx[:, 0] == np.arange(N)).all()
+    for i in range(N):
+        assert set(idx[i, 1:]) == {(i - 1) % N, (i + 1) % N}
+    assert (dist >= 0).all() and np.allclose(dist[:, 0], 0, atol=1e-10)   # test/neighbors.jl:103-107
+    assert (np.diff(dist, axis=1) >= 0).all()
+
+
+def test_grid_radius_8_neighbourhoods(O):
+    # test/topology.jl:43-66: 5x5 grid h=0.1, r=0.15 -> corner 3, edge 5, interior 8; self not in list
+    pts = np.array([(i * 0.1, j * 0.1) for i in range(5) for j in range(5)])
+    for method in ("brute", "kdtree"):
+        off, idx = O.radius(pts, 0.15, method)
+        cnt = np.diff(off).reshape(5, 5)
+        assert cnt[0, 0] == cnt[4, 4] == 3 and cnt[0, 2] == 5 and (cnt[1:4, 1:4] == 8).all()
+        for i in range(25):
+            assert i not in idx[off[i]:off[i + 1]]
+
+
+def test_collinear_25_points(O):
+    # test/metrics.jl:115-143: 25 collinear points spacing 1, k=10 / k=20
+    pts = np.array([(i * 1.0, 0.0, 0.0) for i in range(1, 26)])
+    for k in (10, 20):
+        idx, dist = O.knn(pts, k, False, "kdtree")
+        i = 12  # centre point: distances 1,1,2,2,... with ties broken by index
+        assert np.allclose(dist[i], np.repeat(np.arange(1, k // 2 + 1), 2)[:k])
+        assert list(idx[i][:4]) == [11, 13, 10, 14]
+
+
+def test_k_edge_cases(O):
+    # test/neighbors.jl:156-183: k == N and k == 1 (only self)
+    pts = np.random.default_rng(0).random((5, 3))
+    idx = O.knn(pts, 5, True, "brute", want_dist=False)
+    assert all(sorted(r) == [0, 1, 2, 3, 4] for r in idx)
+    idx = O.knn(np.random.default_rng(1).random((20, 3)), 1, True, "brute", want_dist=False)
+    assert (idx[:, 0] == np.arange(20)).all()
+    with pytest.raises(ValueError):
+        O.knn(pts, 5, False, "brute")  # k+1 > n
+
+
+def test_topology_structure(O):
+    # test/topology.jl:12-41: N lists of exactly k, self never a member
+    pts = np.random.default_rng(2).random((20, 3))
+    idx = O.knn(pts, 5, False, "kdtree", want_dist=False)
+    assert idx.shape == (20, 5) and not (idx == np.arange(20)[:, None]).any()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_force_law_known_answers(O, dtype):
+    # test/repel.jl:117-183
+    for u in (0.0, 0.5, 1.0, 2.0):
+        assert O.force(0, 0.2, 1, 3, u, dtype) == pytest.approx(1 / (u * u + 0.2) ** 2, rel=1e-6)
+        assert O.force(3, 0.2, 1, 3.0, u, dtype) == pytest.approx((1 - u * u) / (u * u + 0.2) ** 3, rel=1e-6)
+        assert O.force(3, 0.2, 1, 2.0, u, dtype) == pytest.approx(O.force(1, 0.2, 1, 3, u, dtype), rel=1e-6)
+    assert O.force(1, 0.2, 1, 3, 1.0, dtype) == 0.0
+    assert O.force(1, 0.2, 1, 3, 0.5, dtype) > 0 > O.force(1, 0.2, 1, 3, 2.0, dtype)
+    for u in (0.0, 0.3, 0.7, 0.99):
+        assert O.force(2, 0.2, 1.0, 3, u, dtype) == pytest.approx(O.force(1, 0.2, 1, 3, u, dtype), rel=1e-6)
+        assert O.force(2, 0.2, 1.0, 3, u, dtype) > 0
+    for u in (1.0, 1.5, 10.0):
+        assert O.force(2, 0.2, 1.0, 3, u, dtype) == 0.0
+    assert O.force(2, 0.2, 0.8, 3, 0.79, dtype) > 0 and O.force(2, 0.2, 0.8, 3, 0.8, dtype) == 0.0
+    assert O.force(3, 0.2, 1, 3.0, 1.0, dtype) == 0.0
+
+
+def test_cull_mask_known_answers(O):
+    # test/repel.jl:301-325
+    pts = np.array([(0.0, 0, 0), (1.0, 0, 0), (2.0, 0, 0), (2.01, 0, 0), (3.0, 0, 0)])
+    keep = O.cull_mask(pts, np.ones(5), 0.5)
+    assert keep.sum() == 4 and keep[2] and not keep[3]
+    assert O.cull_mask(pts, np.ones(5), 0.0).all()
+    cluster = np.array([(10.0 + 1e-3 * i, 0, 0) for i in range(1, 13)])
+    cp = np.concatenate([pts, cluster])
+    ck = O.cull_mask(cp, np.ones(len(cp)), 0.5)
+    assert ck[5:].sum() == 1 and ck[5]
+
+
+def test_relax_loop_stop_rules(O, wtp):
+    # test/repel.jl:262-299, test/float32_pipeline.jl:49-52
+    n = 400
+    x = wtp.synth.uniform(n, 3, np.float32, 5)
+    s = float(n) ** (-1 / 3)
+    kw = dict(k=21, alpha_lo=s / 2000, alpha_max=s / 20)
+    r = O.relax_loop(x, 100, s, max_iters=30, tol=1e-12, stall_after=0, **kw)
+    assert len(r["conv"]) == 30 and r["stop_reason"] == 0           # stall_after=0 burns the budget
+    r = O.relax_loop(x, 100, s, max_iters=200, tol=1e-12, cv_target=10.0, **kw)
+    assert len(r["conv"]) == 1 and r["stop_reason"] == 2             # generous cv_target: 1 iteration...
+    assert np.array_equal(r["p"], x[100:])                           # ...and the cloud comes back untouched
+    r = O.relax_loop(x, 100, s, max_iters=3, tol=1e-6, stall_after=50, **kw)
+    assert len(r["conv"]) == 3 and np.isfinite(r["conv"]).all() and (r["conv"] >= 0).all()
+    # stall stop: a jittered lattice whose pair distances all exceed s is an exact equilibrium of
+    # the clipped law, so the d_NN/s CV cannot improve -> stop after stall_after more iterations
+    g = np.stack(np.meshgrid(*[np.arange(7, dtype=np.float32)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    g += 0.01 * wtp.synth.uniform(len(g), 3, np.float32, 9)
+    r = O.relax_loop(g, 0, 0.9, max_iters=200, tol=0.0, stall_after=5, k=21, alpha_lo=1e-4, alpha_max=0.05)
+    assert len(r["conv"]) == 6 and r["stop_reason"] == 3 and (r["conv"] == 0).all()
+    with pytest.raises(ValueError):
+        O.relax_loop(x, 100, s, max_iters=3, rebuild_every=0, **kw)  # ArgumentError (test/repel.jl:466)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("dim", [2, 3])
+def test_kdtree_equals_brute_and_scipy(O, wtp, dtype, dim):
+    from scipy.spatial import cKDTree
+
+    x = wtp.synth.uniform(4000, dim, dtype, 11)
+    for k, inc in ((21, False), (22, True), (1, True), (7, False)):
+        ib, db = O.knn(x, k, inc, "brute")
+        ik, dk = O.knn(x, k, inc, "kdtree")
+        assert np.array_equal(ib, ik) and np.array_equal(db, dk)
+    d, i = cKDTree(x.astype(np.float64)).query(x.astype(np.float64), 22)
+    ib, db = O.knn(x, 22, True, "brute")
+    agree = (i == ib).all(axis=1)
+    assert agree.mean() > 0.999                                     # tie-free rows agree index for index
+    assert np.allclose(np.sort(d, 1), db, rtol=1e-5 if dtype == np.float32 else 1e-12)
+    off, idx = O.radius(x, 0.07, "brute")
+    off2, idx2 = O.radius(x, 0.07, "kdtree")
+    assert np.array_equal(off, off2) and np.array_equal(idx, idx2)
+    nb = cKDTree(x.astype(np.float64)).query_ball_point(x.astype(np.float64)[:200], 0.07)
+    for q in range(200):
+        mine = set(idx[off[q]:off[q + 1]])
+        # pairs within 4 ulp of the radius may differ between float types
+        assert len(mine ^ (set(nb[q]) - {q})) <= (1 if dtype == np.float32 else 0)
+
+
+def test_numpy_brute_force_ties_by_index(O):
+    # lattice: every shell is a tie; canonical order = (d2, index)
+    g = np.stack(np.meshgrid(*[np.arange(6.0)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    idx, _ = O.knn(g, 10, False, "kdtree")
+    d2 = ((g[:, None, :] - g[None, :, :]) ** 2).sum(-1)
+    np.fill_diagonal(d2, np.inf)
+    order = np.lexsort((np.broadcast_to(np.arange(len(g)), d2.shape), d2), axis=1)[:, :10]
+    assert np.array_equal(idx, order)
+
+
+def test_spacing_laws(O):
+    # src/discretization/spacings.jl:67-72,121-133 against their closed forms
+    bnd = np.array([[0.0, 0, 0], [1.0, 0, 0]])
+    q = np.array([[0.5, 0.3, 0.0], [0.1, 0.0, 0.0]])
+    d = np.array([math.hypot(0.5, 0.3), 0.1])
+    out = O.spacing_loglike(q, bnd, 0.2, 1.3)
+    assert np.allclose(out, 0.2 * d / (0.2 * (1 - 0.3) + d))
+    out = O.spacing_boundary_layer(q, bnd, 0.05, 0.4, 0.6)
+    assert np.allclose(out, 0.05 + 0.35 / (1 + np.exp(-(d - 0.3) / 0.1)))
+
+
+def test_generator_three_implementations_agree(O, wtp):
+    a = wtp.synth.uniform(5000, 3, np.float32, 20260821, first=17)
+    b = O.gen_uniform(20260821, 5000, 3, np.float32, first=17)
+    assert np.array_equal(a, b) and a.min() >= 0 and a.max() < 1

@@ -48,6 +48,8 @@ class _HasTopology:
 
     def rebuild_topology(self, ctx=None):
         """In place, same parameters; no-op for NoTopology (src/cloud.jl:224-228)."""
+        if isinstance(self.topology, T.NoTopology):
+            return None
         T.rebuild_topology(ctx or default_context(), self.topology, self.points())
         return None
 

@@ -367,9 +367,9 @@ static int pick_free(const RelaxState& r, int avoid_a, int avoid_b) {
     return 0;
 }
 
-WTP_API int wtp_relax_init(wtp_ctx* ctx, const void* snap_xyz, int64_t n, int64_t n_fixed, int dim, int dtype,
-                   const wtp_spacing_desc* spacing, const wtp_force_desc* force, int k, double alpha_lo,
-                   double alpha_max) {
+static int relax_init_impl(wtp_ctx* ctx, const void* snap_xyz, bool on_device, int64_t n, int64_t n_fixed, int dim,
+                           int dtype, const wtp_spacing_desc* spacing, const wtp_force_desc* force, int k,
+                           double alpha_lo, double alpha_max) {
     int rc = check_cloud(ctx, snap_xyz, n, dim, dtype);
     if (rc) return rc;
     if (n_fixed < 0 || n_fixed > n) return fail(ctx, WTP_ERR_ARG, "n_fixed must be in [0, n]");
@@ -403,7 +403,8 @@ WTP_API int wtp_relax_init(wtp_ctx* ctx, const void* snap_xyz, int64_t n, int64_
     if ((rc = ensure(ctx, ctx->fb_count, 64))) return rc;
     const int n_partials = brick_partials() + kGenericPartials;
     if ((rc = ensure(ctx, ctx->partials, sizeof(Partial) * (size_t)n_partials))) return rc;
-    WTP_HIP(ctx, hipMemcpyAsync(ctx->raw_in.p, snap_xyz, ts * (size_t)n * dim, hipMemcpyHostToDevice, ctx->stream));
+    WTP_HIP(ctx, hipMemcpyAsync(ctx->raw_in.p, snap_xyz, ts * (size_t)n * dim,
+                                on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
     if (dtype == WTP_F32)
         rc = load_points<float>(ctx, (const float*)ctx->raw_in.p, (float4*)ctx->pts[0].p, n, dim);
     else
@@ -433,6 +434,18 @@ WTP_API int wtp_relax_init(wtp_ctx* ctx, const void* snap_xyz, int64_t n, int64_
     r.bufS = -1;
     r.bufOld = -1;
     return WTP_OK;
+}
+
+WTP_API int wtp_relax_init(wtp_ctx* ctx, const void* snap_xyz, int64_t n, int64_t n_fixed, int dim, int dtype,
+                           const wtp_spacing_desc* spacing, const wtp_force_desc* force, int k, double alpha_lo,
+                           double alpha_max) {
+    return relax_init_impl(ctx, snap_xyz, false, n, n_fixed, dim, dtype, spacing, force, k, alpha_lo, alpha_max);
+}
+
+WTP_API int wtp_relax_init_dev(wtp_ctx* ctx, const void* d_snap_xyz, int64_t n, int64_t n_fixed, int dim, int dtype,
+                               const wtp_spacing_desc* spacing, const wtp_force_desc* force, int k,
+                               double alpha_lo, double alpha_max) {
+    return relax_init_impl(ctx, d_snap_xyz, true, n, n_fixed, dim, dtype, spacing, force, k, alpha_lo, alpha_max);
 }
 
 template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_step_stats* d_slot) {

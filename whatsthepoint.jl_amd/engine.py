@@ -100,8 +100,8 @@ class Context:
         return offsets, idx[: int(offsets[-1])]
 
     # ---- repel -------------------------------------------------------------------------------
-    def relax(self, snap, n_fixed: int, spacing, force, k: int, alpha_lo: float, alpha_max: float):
-        return RelaxSession(self, snap, n_fixed, spacing, force, k, alpha_lo, alpha_max)
+    def relax(self, snap, n_fixed: int, spacing, force, k: int, alpha_lo: float, alpha_max: float, device_ptr=None):
+        return RelaxSession(self, snap, n_fixed, spacing, force, k, alpha_lo, alpha_max, device_ptr=device_ptr)
 
     # ---- measurement ---------------------------------------------------------------------------
     def timers(self):
@@ -127,12 +127,19 @@ class RelaxSession:
     """Device-resident state of one `_relax!` call (src/repel.jl:202-339): coordinates stay in
     HBM between sweeps; the host sees three scalars per iteration."""
 
-    def __init__(self, ctx: Context, snap, n_fixed: int, spacing, force, k: int, alpha_lo: float, alpha_max: float):
+    def __init__(self, ctx: Context, snap, n_fixed: int, spacing, force, k: int, alpha_lo: float, alpha_max: float,
+                 device_ptr=None):
+        """snap: host (n, dim) array — or, with device_ptr=(ptr, n, dim, dtype), a snapshot that is
+        already resident on the context's GPU (bench / sharded driver)."""
         self.ctx = ctx
         self._lib = ctx._lib
-        snap = _cloud(snap)
-        self.n, self.dim = snap.shape
-        self.dtype = snap.dtype
+        if device_ptr is None:
+            snap = _cloud(snap)
+            self.n, self.dim = snap.shape
+            self.dtype = snap.dtype
+        else:
+            _, self.n, self.dim, dt = device_ptr
+            self.dtype = np.dtype(dt)
         self.n_fixed = int(n_fixed)
         sd = L.SpacingDesc()
         self._sp_keep = None
@@ -146,8 +153,13 @@ class RelaxSession:
             sd.kind, sd.constant, sd.per_point = 1, 0.0, sp.ctypes.data
         fd = L.ForceDesc(int(force["kind"]), float(force["beta"]), float(force.get("u0", 1.0)),
                          float(force.get("gamma", 3.0)))
-        rc = self._lib.wtp_relax_init(ctx._h, _vp(snap), self.n, self.n_fixed, self.dim, _dtype_code(self.dtype),
-                                      C.byref(sd), C.byref(fd), int(k), float(alpha_lo), float(alpha_max))
+        if device_ptr is None:
+            rc = self._lib.wtp_relax_init(ctx._h, _vp(snap), self.n, self.n_fixed, self.dim, _dtype_code(self.dtype),
+                                          C.byref(sd), C.byref(fd), int(k), float(alpha_lo), float(alpha_max))
+        else:
+            rc = self._lib.wtp_relax_init_dev(ctx._h, C.c_void_p(device_ptr[0]), self.n, self.n_fixed, self.dim,
+                                              _dtype_code(self.dtype), C.byref(sd), C.byref(fd), int(k),
+                                              float(alpha_lo), float(alpha_max))
         L.check(ctx._h, rc)
         self._open = True
 
