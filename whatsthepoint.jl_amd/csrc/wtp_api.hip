@@ -120,6 +120,8 @@ static int knn_dev_t(wtp_ctx* ctx, const T* d_xyz, int64_t n, int dim, int k, in
     if ((rc = ensure(ctx, ctx->pts[1], sizeof(Pt<T>) * (size_t)n))) return rc;
     if ((rc = ensure(ctx, ctx->fb_list, sizeof(int32_t) * (size_t)n))) return rc;
     if ((rc = ensure(ctx, ctx->fb_count, 64))) return rc;
+    if ((rc = ensure(ctx, ctx->fb2_list, sizeof(int32_t) * (size_t)n))) return rc;
+    if ((rc = ensure(ctx, ctx->fb2_count, 64))) return rc;
     Pt<T>* raw = (Pt<T>*)ctx->pts[0].p;
     Pt<T>* sorted = (Pt<T>*)ctx->pts[1].p;
     int sp = span_begin(ctx, 0);
@@ -139,6 +141,8 @@ static int knn_dev_t(wtp_ctx* ctx, const T* d_xyz, int64_t n, int dim, int k, in
     a.dist_out = d_dist;
     a.fb_list = (int32_t*)ctx->fb_list.p;
     a.fb_count = (int32_t*)ctx->fb_count.p;
+    a.fb2_list = (int32_t*)ctx->fb2_list.p;
+    a.fb2_count = (int32_t*)ctx->fb2_count.p;
     sp = span_begin(ctx, 1);
     rc = launch_topology<T>(ctx, a);
     span_end(ctx, sp);
@@ -215,7 +219,7 @@ WTP_API int wtp_destroy(wtp_ctx* ctx) {
                       &ctx->cell_cnt, &ctx->cell_start, &ctx->scan_tmp, &ctx->grid, &ctx->bbox_part,
                       &ctx->idx_out, &ctx->dist_out, &ctx->counts_out, &ctx->forces, &ctx->nn_dist,
                       &ctx->nn_id, &ctx->spacing_pp, &ctx->partials, &ctx->stats, &ctx->fb_list,
-                      &ctx->fb_count, &ctx->scratch};
+                      &ctx->fb_count, &ctx->fb2_list, &ctx->fb2_count, &ctx->scratch};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     if (ctx->host_pinned) hipHostFree(ctx->host_pinned);
@@ -401,7 +405,9 @@ static int relax_init_impl(wtp_ctx* ctx, const void* snap_xyz, bool on_device, i
     if ((rc = ensure(ctx, ctx->nn_id, sizeof(int32_t) * (size_t)n))) return rc;
     if ((rc = ensure(ctx, ctx->fb_list, sizeof(int32_t) * (size_t)n))) return rc;
     if ((rc = ensure(ctx, ctx->fb_count, 64))) return rc;
-    const int n_partials = brick_partials() + kGenericPartials;
+    if ((rc = ensure(ctx, ctx->fb2_list, sizeof(int32_t) * (size_t)n))) return rc;
+    if ((rc = ensure(ctx, ctx->fb2_count, 64))) return rc;
+    const int n_partials = total_partials();
     if ((rc = ensure(ctx, ctx->partials, sizeof(Partial) * (size_t)n_partials))) return rc;
     WTP_HIP(ctx, hipMemcpyAsync(ctx->raw_in.p, snap_xyz, ts * (size_t)n * dim,
                                 on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
@@ -489,9 +495,11 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
     a.force_kind = r.force.kind;
     a.n_fixed = (int32_t)r.n_fixed;
     a.partials = (Partial*)ctx->partials.p;
-    a.n_partials = brick_partials() + kGenericPartials;
+    a.n_partials = total_partials();
     a.fb_list = (int32_t*)ctx->fb_list.p;
     a.fb_count = (int32_t*)ctx->fb_count.p;
+    a.fb2_list = (int32_t*)ctx->fb2_list.p;
+    a.fb2_count = (int32_t*)ctx->fb2_count.p;
     if ((rc = launch_sweep<T>(ctx, a, fresh))) return rc;
     int sp = span_begin(ctx, 2);
     rc = launch_reduce_partials(ctx, a.partials, a.n_partials, a.fb_count, d_slot);

@@ -159,10 +159,21 @@ static inline int blocks_for(int64_t n, int cap) {
     return (int)(b > cap ? cap : b);
 }
 
+// Exact path = wave-per-query kernel over the list (or all points), then this serial kernel over
+// whatever the wave kernel could not buffer (fb2 list).  WTP_FORCE_GENERIC=2 runs everything
+// through the serial kernel (debug).
 template <typename T> int launch_generic_topology(wtp_ctx* ctx, SearchArgs<T>& a, bool all) {
-    const int nb = blocks_for(a.n, all ? 65536 : 1024);
-    hipLaunchKernelGGL((generic_kernel<T, 0>), dim3(nb), dim3(kThreads), 0, ctx->stream, a, a.fb_list,
-                       a.fb_count, all ? 1 : 0, 0);
+    WTP_HIP(ctx, hipMemsetAsync(a.fb2_count, 0, sizeof(int32_t), ctx->stream));
+    if (ctx->force_generic == 2) {
+        hipLaunchKernelGGL((generic_kernel<T, 0>), dim3(blocks_for(a.n, all ? 65536 : 1024)), dim3(kThreads), 0,
+                           ctx->stream, a, a.fb_list, a.fb_count, all ? 1 : 0, 0);
+        WTP_HIP(ctx, hipGetLastError());
+        return WTP_OK;
+    }
+    int rc = launch_wave_topology<T>(ctx, a, all);
+    if (rc) return rc;
+    hipLaunchKernelGGL((generic_kernel<T, 0>), dim3(256), dim3(kThreads), 0, ctx->stream, a, a.fb2_list,
+                       a.fb2_count, 0, 0);
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;
 }
@@ -171,11 +182,19 @@ template <typename T> int launch_generic_topology(wtp_ctx* ctx, SearchArgs<T>& a
 // this one.
 
 template <typename T> int launch_generic_sweep(wtp_ctx* ctx, SearchArgs<T>& a, bool all) {
-    const int nb = blocks_for(a.n, all ? kGenericPartials : 1024);
     const int part_base = a.n_partials - kGenericPartials;
-    // blocks beyond nb never run: their partial slots are cleared by the caller's memset
-    hipLaunchKernelGGL((generic_kernel<T, 1>), dim3(nb), dim3(kThreads), 0, ctx->stream, a, a.fb_list,
-                       a.fb_count, all ? 1 : 0, part_base);
+    // partial slots of blocks that never run were cleared by the caller's memset
+    WTP_HIP(ctx, hipMemsetAsync(a.fb2_count, 0, sizeof(int32_t), ctx->stream));
+    if (ctx->force_generic == 2) {
+        hipLaunchKernelGGL((generic_kernel<T, 1>), dim3(blocks_for(a.n, kGenericPartials)), dim3(kThreads), 0,
+                           ctx->stream, a, a.fb_list, a.fb_count, all ? 1 : 0, part_base);
+        WTP_HIP(ctx, hipGetLastError());
+        return WTP_OK;
+    }
+    int rc = launch_wave_sweep<T>(ctx, a, all);
+    if (rc) return rc;
+    hipLaunchKernelGGL((generic_kernel<T, 1>), dim3(256), dim3(kThreads), 0, ctx->stream, a, a.fb2_list,
+                       a.fb2_count, 0, part_base);
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;
 }

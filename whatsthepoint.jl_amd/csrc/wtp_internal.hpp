@@ -56,8 +56,9 @@ constexpr int BX = 4, BY = 4, BZ = 4;
 constexpr int HX = BX + 2, HY = BY + 2, HZ = BZ + 2;
 constexpr int HCELLS = HX * HY * HZ;
 constexpr int kBrickThreads = 256;
-// partial-reduction slots: [0, brick_partials()) brick kernel blocks, then kGenericPartials
-constexpr int kGenericPartials = 4096;
+// partial-reduction slots: [0, brick_partials()) brick blocks, then kWavePartials, then kGenericPartials
+constexpr int kWavePartials = 4096;    // wave-per-query kernel blocks
+constexpr int kGenericPartials = 1024; // serial last-resort kernel blocks
 int brick_partials();
 constexpr int kGenericKMax = 128; // largest k the library accepts (generic kernel's list)
 
@@ -105,6 +106,8 @@ template <typename T> struct SearchArgs {
     // fallback work list
     int32_t* fb_list;
     int32_t* fb_count;
+    int32_t* fb2_list;         // second level: wave kernel -> serial kernel
+    int32_t* fb2_count;
     // tunables
     T gamma_cap;               // initial filter radius cap, in cell edges
 };
@@ -146,7 +149,7 @@ struct wtp_ctx {
     wtp::DevBuf grid, bbox_part;
     wtp::DevBuf idx_out, dist_out, counts_out;
     wtp::DevBuf forces, nn_dist, nn_id, spacing_pp;
-    wtp::DevBuf partials, stats, fb_list, fb_count;
+    wtp::DevBuf partials, stats, fb_list, fb_count, fb2_list, fb2_count;
     wtp::DevBuf scratch;       // misc (relax_get staging, radius rows)
     void* host_pinned = nullptr;
     size_t host_pinned_cap = 0;
@@ -196,8 +199,12 @@ int load_points(wtp_ctx* ctx, const T* d_xyz, Pt<T>* out, int64_t n, int dim);
 
 template <typename T> int launch_topology(wtp_ctx* ctx, SearchArgs<T>& a);
 template <typename T> int launch_sweep(wtp_ctx* ctx, SearchArgs<T>& a, bool fresh);
+// exact paths: wave-per-query (list = fb_list or all points), then the serial kernel on fb2_list
+template <typename T> int launch_wave_topology(wtp_ctx* ctx, SearchArgs<T>& a, bool all);
+template <typename T> int launch_wave_sweep(wtp_ctx* ctx, SearchArgs<T>& a, bool all);
 template <typename T> int launch_generic_topology(wtp_ctx* ctx, SearchArgs<T>& a, bool all);
 template <typename T> int launch_generic_sweep(wtp_ctx* ctx, SearchArgs<T>& a, bool all);
+inline int total_partials() { return brick_partials() + kWavePartials + kGenericPartials; }
 template <typename T>
 int launch_radius_count(wtp_ctx* ctx, SearchArgs<T>& a, T r, int32_t* d_counts);
 template <typename T>

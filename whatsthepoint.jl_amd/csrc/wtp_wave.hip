@@ -1,0 +1,281 @@
+// wtp_wave.hip — exact wave-per-query search (gfx950): one 64-lane wavefront owns one query.
+//
+// Serves every query the 27-cell brick kernels hand back, and whole sweeps the brick path does
+// not cover (fp64, k > 48, stale snapshots of rebuild_every > 1, src/repel.jl:245,262-266).
+//   gather   the wave walks the x-rows of the (2r+1)^dim cell block around the query's cell;
+//            each row is one contiguous run of the sorted Pt array, read 64 points per step
+//            (coalesced 16/32-B loads).  Candidates inside the provable radius are appended to a
+//            per-wave LDS list with ballot + mbcnt prefix sums.
+//   select   the k-th smallest d2 is found by bisection on the d2 bit pattern (monotone for
+//            d2 >= 0): count(d2 <= mid) is a ballot + s_bcnt per 64 candidates, keys held in
+//            VGPRs.  Survivors (d2 <= cut) are ranked by the canonical (d2, index) order with a
+//            broadcast compare loop, giving the sorted first k.
+//   emit     MODE 0 writes the row (coalesced); MODE 1 evaluates the k contributions in
+//            parallel, then lane 0 adds them in ascending order exactly like
+//            src/repel.jl:270-280, steps the point (:282-291) and accumulates the reductions.
+// Rings grow (r = 2, 4, ...) until the k-th hit is provably final.  A candidate list larger
+// than the LDS buffer sends the query to the serial kernel of wtp_generic.hip.
+#include "wtp_device.hpp"
+
+namespace wtp {
+
+static constexpr int kWaves = 4;             // waves per workgroup
+static constexpr int kThreads = kWaves * 64;
+static constexpr int kCap = 1024;            // candidates buffered per wave
+static constexpr int kKeyRegs = kCap / 64;
+static constexpr int kSurv = 256;            // survivors (d2 <= cut) ranked per wave
+
+template <typename T> struct Bits;
+template <> struct Bits<float> {
+    using U = uint32_t;
+    static __device__ U of(float v) { return __builtin_bit_cast(uint32_t, v); }
+    static __device__ float back(U u) { return __builtin_bit_cast(float, u); }
+    static constexpr U kInf = 0x7F800000u;
+};
+template <> struct Bits<double> {
+    using U = uint64_t;
+    static __device__ U of(double v) { return __builtin_bit_cast(uint64_t, v); }
+    static __device__ double back(U u) { return __builtin_bit_cast(double, u); }
+    static constexpr U kInf = 0x7FF0000000000000ull;
+};
+
+template <typename T> struct WaveSmem {
+    T d2[kCap];
+    int32_t id[kCap];
+    int32_t slot[kCap];
+    T sd2[kSurv];       // survivors
+    int32_t sid[kSurv];
+    int32_t sslot[kSurv];
+    T od2[kGenericKMax]; // sorted first k
+    int32_t oid[kGenericKMax];
+    int32_t oslot[kGenericKMax];
+    T fx[kGenericKMax], fy[kGenericKMax], fz[kGenericKMax];
+};
+
+__device__ inline int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0)); }
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const int32_t* __restrict__ list,
+                                                        const int32_t* __restrict__ list_count, int all,
+                                                        int part_base) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    using U = typename Bits<T>::U;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    WaveSmem<T>* sm = reinterpret_cast<WaveSmem<T>*>(smem_raw) + wave;
+    Acc* sm_acc = reinterpret_cast<Acc*>(smem_raw + sizeof(WaveSmem<T>) * kWaves);
+    const Grid<T> g = *a.grid;
+    const int nq = all ? a.n : *list_count;
+    const int K = a.k;
+    const bool skip_self = (MODE == 0) && !a.include_self;
+    Acc acc = acc_empty();
+    const int wave_global = blockIdx.x * kWaves + wave;
+    const int wave_stride = gridDim.x * kWaves;
+
+    for (int qi = wave_global; qi < nq; qi += wave_stride) {
+        const int slot = all ? qi : list[qi];
+        const Pt<T> q = a.query[slot];
+        const int32_t id = w_to_id(q.w);
+        if (MODE == 1 && id < a.n_fixed) {
+            if (lane == 0) {
+                a.out[slot] = q;
+                a.forces[slot] = (T)0;
+                a.nn_dist[slot] = Lim<T>::inf();
+                a.nn_id[slot] = -1;
+            }
+            continue;
+        }
+        const int cx = cell_coord(g, q.x, 0), cy = cell_coord(g, q.y, 1), cz = cell_coord(g, q.z, 2);
+        int m = 0;
+        bool overflow = false;
+        for (int r = 2;; r *= 2) {
+            m = 0;
+            const T g2 = safe_radius2(g, q.x, q.y, q.z, cx, cy, cz, r);
+            const int z0 = cz - r < 0 ? 0 : cz - r, z1 = cz + r > g.n[2] - 1 ? g.n[2] - 1 : cz + r;
+            const int y0 = cy - r < 0 ? 0 : cy - r, y1 = cy + r > g.n[1] - 1 ? g.n[1] - 1 : cy + r;
+            const int x0 = cx - r < 0 ? 0 : cx - r, x1 = cx + r > g.n[0] - 1 ? g.n[0] - 1 : cx + r;
+            for (int z = z0; z <= z1 && !overflow; ++z)
+                for (int y = y0; y <= y1 && !overflow; ++y) {
+                    const int row = (z * g.n[1] + y) * g.n[0];
+                    const int ps = a.cell_start[row + x0], pe = a.cell_start[row + x1 + 1];
+                    for (int p0 = ps; p0 < pe; p0 += 64) {
+                        const int p = p0 + lane;
+                        bool take = false;
+                        T d = 0;
+                        int32_t cid = 0;
+                        if (p < pe) {
+                            const Pt<T> c = a.snap[p];
+                            cid = w_to_id(c.w);
+                            d = dist2<T>(q.x, q.y, q.z, c.x, c.y, c.z);
+                            take = (d <= g2) && !(skip_self && cid == id);
+                        }
+                        const unsigned long long mask = __ballot(take);
+                        const int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
+                        if (take && pos < kCap) {
+                            sm->d2[pos] = d;
+                            sm->id[pos] = cid;
+                            sm->slot[pos] = p;
+                        }
+                        m += __popcll(mask);
+                        if (m > kCap) {
+                            overflow = true;
+                            break;
+                        }
+                    }
+                }
+            if (overflow) break;
+            if (m >= K) break;                       // everything inside g2 is known: the k-th is final
+            if (g2 == Lim<T>::inf()) break;          // block covers the grid
+        }
+        if (overflow || m < K) { // m < K only when fewer than k points exist in reach (validated upstream)
+            if (lane == 0) {
+                const int pos = atomicAdd(a.fb2_count, 1);
+                a.fb2_list[pos] = slot;
+            }
+            continue;
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- select: k-th smallest d2 by bisection over bit patterns, keys in registers --------
+        U key[kKeyRegs];
+#pragma unroll
+        for (int j = 0; j < kKeyRegs; ++j) {
+            const int i = j * 64 + lane;
+            key[j] = i < m ? Bits<T>::of(sm->d2[i]) : ~(U)0;
+        }
+        U lo = 0, hi = Bits<T>::kInf;
+        while (lo < hi) {
+            const U mid = lo + (hi - lo) / 2;
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < kKeyRegs; ++j)
+                if (j * 64 < m) cnt += __popcll(__ballot(key[j] <= mid));
+            if (cnt >= K)
+                hi = mid;
+            else
+                lo = mid + 1;
+        }
+        const U cut = lo;
+        // ---- survivors: d2 <= cut (k of them, more only on ties at the cut) --------------------------
+        int ns = 0;
+#pragma unroll
+        for (int j = 0; j < kKeyRegs; ++j) {
+            if (j * 64 < m) {
+                const int i = j * 64 + lane;
+                const bool take = key[j] <= cut;
+                const unsigned long long mask = __ballot(take);
+                const int pos = ns + __popcll(mask & ((1ull << lane) - 1ull));
+                if (take && pos < kSurv) {
+                    sm->sd2[pos] = sm->d2[i];
+                    sm->sid[pos] = sm->id[i];
+                    sm->sslot[pos] = sm->slot[i];
+                }
+                ns += __popcll(mask);
+            }
+        }
+        if (ns > kSurv) { // a mass tie at the cut: serial kernel
+            if (lane == 0) {
+                const int pos = atomicAdd(a.fb2_count, 1);
+                a.fb2_list[pos] = slot;
+            }
+            continue;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- canonical rank among survivors -> sorted first k ----------------------------------------
+        for (int i = lane; i < ns; i += 64) {
+            const T md = sm->sd2[i];
+            const int32_t mi = sm->sid[i];
+            int rank = 0;
+            for (int j = 0; j < ns; ++j) rank += lex_lt(sm->sd2[j], sm->sid[j], md, mi) ? 1 : 0;
+            if (rank < K) {
+                sm->od2[rank] = md;
+                sm->oid[rank] = mi;
+                sm->oslot[rank] = sm->sslot[i];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        if (MODE == 0) {
+            for (int j = lane; j < K; j += 64) {
+                a.idx_out[(int64_t)id * K + j] = sm->oid[j];
+                if (a.dist_out) a.dist_out[(int64_t)id * K + j] = wsqrt(sm->od2[j]);
+            }
+        } else {
+            const T s = a.spacing_pp ? a.spacing_pp[id] : a.spacing_const;
+            for (int j = lane; j < K; j += 64) {
+                T fx = 0, fy = 0, fz = 0;
+                if (sm->oid[j] != id) {
+                    const Pt<T> c = a.snap[sm->oslot[j]];
+                    add_force<T>(a, g.dim, s, q.x, q.y, q.z, id, c.x, c.y, c.z, sm->oid[j], sm->od2[j], fx, fy, fz);
+                }
+                sm->fx[j] = fx;
+                sm->fy[j] = fy;
+                sm->fz[j] = fz;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                T Fx = 0, Fy = 0, Fz = 0;
+                int32_t nid = -1;
+                T nd = Lim<T>::inf();
+                for (int j = 0; j < K; ++j) { // ascending (d2, id), self skipped by index (:271)
+                    if (sm->oid[j] == id) continue;
+                    if (nid < 0) {
+                        nid = sm->oid[j];
+                        nd = wsqrt(sm->od2[j]);
+                    }
+                    Fx = Fx + sm->fx[j];
+                    Fy = Fy + sm->fy[j];
+                    Fz = Fz + sm->fz[j];
+                }
+                Pt<T> o;
+                const T f = step_point<T>(a, s, q.x, q.y, q.z, Fx, Fy, Fz, o.x, o.y, o.z);
+                o.w = q.w;
+                a.out[slot] = o;
+                a.forces[slot] = f;
+                a.nn_dist[slot] = nd;
+                a.nn_id[slot] = nid;
+                acc_point(acc, (double)f, (double)nd, (double)s, id, nid);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (MODE == 1) {
+        __syncthreads();
+        acc_block_reduce(acc, sm_acc);
+        if (threadIdx.x == 0) acc_store(&a.partials[part_base + blockIdx.x], acc);
+    }
+}
+
+template <typename T> static size_t wave_smem() { return sizeof(WaveSmem<T>) * kWaves + sizeof(Acc) * kWaves; }
+
+template <typename T, int MODE> static int launch_wave(wtp_ctx* ctx, SearchArgs<T>& a, bool all, int part_base) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)wave_kernel<T, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)wave_smem<T>());
+        attr_set = true;
+    }
+    int64_t want = all ? ((int64_t)a.n + kWaves - 1) / kWaves : 2048;
+    int nb = (int)(want > kWavePartials ? kWavePartials : (want < 1 ? 1 : want));
+    hipLaunchKernelGGL((wave_kernel<T, MODE>), dim3(nb), dim3(kThreads), wave_smem<T>(), ctx->stream, a, a.fb_list,
+                       a.fb_count, all ? 1 : 0, part_base);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
+template <typename T> int launch_wave_topology(wtp_ctx* ctx, SearchArgs<T>& a, bool all) {
+    return launch_wave<T, 0>(ctx, a, all, 0);
+}
+
+template <typename T> int launch_wave_sweep(wtp_ctx* ctx, SearchArgs<T>& a, bool all) {
+    return launch_wave<T, 1>(ctx, a, all, brick_partials());
+}
+
+#define INST(T)                                                               \
+    template int launch_wave_topology<T>(wtp_ctx*, SearchArgs<T>&, bool);     \
+    template int launch_wave_sweep<T>(wtp_ctx*, SearchArgs<T>&, bool);
+INST(float)
+INST(double)
+#undef INST
+
+} // namespace wtp
