@@ -1,33 +1,36 @@
 // wtp_brick.hip — the hot kernels: 27-cell k-NN with the candidates staged in LDS (gfx950, fp32).
 //
 // One 256-thread workgroup sweeps a brick of BX x BY x BZ cells.  It stages the brick's
-// (BX+2)(BY+2)(BZ+2) halo cells from the sorted Pt array into LDS (16-B ds_read_b128 per
+// (BX+2)(BY+2)(BZ+2) halo cells from the sorted Pt array into LDS (one ds_read_b128 per
 // candidate afterwards), then every lane owns one query at a time:
-//   scan      the 9 x-rows of its 3x3x3 neighbourhood; candidates with d2 <= tau are appended
-//             (LDS slot, 16 bit) to a per-lane ring in LDS.  tau starts at
+//   scan      the 9 x-rows of its 3x3x3 neighbourhood, 4 candidates per step, straight-line:
+//             candidates with d2 <= tau are appended (16-bit LDS slot) to a per-lane ring in LDS
+//             through a branch-free "dump row" store.  tau starts at
 //             min(provable radius, gamma_cap * cell)^2, so whatever is kept is exact.
-//   select    keys (d2 bit patterns, monotone for d2 >= 0) go through a 64-wide Batcher
-//             network held in VGPRs; the k-th key is the cut.
-//   topology  MODE 0: 64-bit keys (d2 bits << 32 | id) sort the survivors canonically and the
-//             first k are written as the row of the query's original id
-//             (_build_knn_neighbors, src/topology.jl:79-84).
-//   sweep     MODE 1: the Miotti force of src/repel.jl:270-291 is accumulated over the cut set
-//             in the same pass structure, the point is stepped, and max|F|s, sum u, sum u^2
-//             and the closest pair are reduced per wave with shuffles (src/repel.jl:293,374-403).
+//   select    ring keys (d2 bit patterns, monotone for d2 >= 0) go through a 64-wide Batcher
+//             network held in VGPRs (integer min/max); the k-th key is the cut.  With k known
+//             at compile time (k = 21, the reference default) dead comparators are eliminated.
+//             The same code instance serves ring-pressure prunes and the final selection.
+//   topology  MODE 0: survivors (d2 <= cut) are compacted and a 32-wide network on 64-bit keys
+//             (d2 bits << 32 | id) gives the canonical order; the first k are the row of the
+//             query's original id (_build_knn_neighbors, src/topology.jl:79-84).
+//   sweep     MODE 1: the Miotti force of src/repel.jl:270-291 is accumulated over the cut set,
+//             the point is stepped, and max|F|s, sum u, sum u^2 and the closest pair are reduced
+//             per wave with shuffles (src/repel.jl:293,374-403).
 // Queries the fast path cannot certify (k-th hit beyond the provable radius, a tie exactly at
-// the cut, ring overflow, halo larger than LDS) are appended to a work list for
-// wtp_generic.hip; results are therefore always the exact canonical lists.
+// the cut, ring overflow, halo larger than LDS) are appended to a work list for wtp_wave.hip;
+// results are therefore always the exact canonical lists.
 //
-// Roofline: this kernel streams 16 B/point in and 28 B/point out (MODE 1) — its HBM floor is
-// ~0.07 ms for 10 M points — but does ~5-6 k VALU lane-ops per query, so it is bound by the
-// vector ALU and LDS issue rate, not by HBM.
+// Roofline: the kernel streams 16 B/point in and 28 B/point out (MODE 1) — its HBM floor is
+// ~0.07 ms for 10 M points — but executes several thousand VALU lane-ops per query, so it is
+// bound by vector-ALU and LDS issue, not by HBM.
 #include "wtp_device.hpp"
 #include "wtp_sortnet.hpp"
 
 namespace wtp {
 
 constexpr int NB = 64;          // per-lane candidate ring / sorting-network width
-constexpr int kFastKMax = 48;   // k beyond this goes to the generic kernel
+constexpr int kFastKMax = 32;   // k >= this goes to the wave kernel
 constexpr int kOwnRows = BY * BZ;
 
 struct BrickSmem {
@@ -49,70 +52,86 @@ struct BrickSmem {
 __device__ inline uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 __device__ inline float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 
-// d2 of ring entry j of this lane, +inf bits when j >= cnt
-__device__ inline uint32_t ring_key(const float4* __restrict__ pts, const uint16_t* __restrict__ ring, int j,
-                                    int cnt, float qx, float qy, float qz) {
-    if (j >= cnt) return 0x7F800000u;
-    const float4 c = pts[ring[j * kBrickThreads]];
-    return f2u(dist2<float>(qx, qy, qz, c.x, c.y, c.z));
-}
-
-// Sort this lane's ring keys; return k-th smallest (index K-1) and the next one (index K).
+// Sort this lane's ring keys (d2 recomputed from the staged points); return the k-th smallest
+// (index K-1) and the next one (index K).  KT > 0: K is the compile-time KT.
+template <int KT>
 __device__ inline void ring_select(const float4* __restrict__ pts, const uint16_t* __restrict__ ring, int cnt,
                                    float qx, float qy, float qz, int K, uint32_t& kth, uint32_t& next) {
     uint32_t k[NB];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) k[j] = ring_key(pts, ring, j, cnt, qx, qy, qz);
-    WTP_SORTNET_64(k)
-    kth = k[0];
-    next = k[1];
+    for (int c8 = 0; c8 < NB / 8; ++c8) {
+        if (__any(cnt > c8 * 8)) { // wave-uniform: skip chunks no lane has filled
 #pragma unroll
-    for (int j = 1; j < NB - 1; ++j) {
-        kth = (j == K - 1) ? k[j] : kth;
-        next = (j == K - 1) ? k[j + 1] : next;
+            for (int j = c8 * 8; j < c8 * 8 + 8; ++j) {
+                const float4 c = pts[ring[(j < cnt ? j : 0) * kBrickThreads]];
+                const uint32_t d = f2u(dist2<float>(qx, qy, qz, c.x, c.y, c.z));
+                k[j] = j < cnt ? d : 0x7F800000u;
+            }
+        } else {
+#pragma unroll
+            for (int j = c8 * 8; j < c8 * 8 + 8; ++j) k[j] = 0x7F800000u;
+        }
+    }
+    WTP_SORTNET_64(k)
+    if (KT > 0) {
+        kth = k[KT - 1];
+        next = k[KT];
+    } else {
+        kth = k[0];
+        next = k[1];
+#pragma unroll
+        for (int j = 1; j < kFastKMax; ++j) {
+            kth = (j == K - 1) ? k[j] : kth;
+            next = (j == K - 1) ? k[j + 1] : next;
+        }
     }
 }
 
-// Tighten tau to the k-th smallest so far and drop ring entries beyond it.
-__device__ inline void ring_prune(const float4* __restrict__ pts, uint16_t* __restrict__ ring, int& cnt,
-                                  float& tau, float qx, float qy, float qz, int K) {
-    uint32_t kth, next;
-    ring_select(pts, ring, cnt, qx, qy, qz, K, kth, next);
-    if (cnt >= K) {
-        const float t = u2f(kth);
-        tau = t < tau ? t : tau;
-    }
+// Keep ring entries with d2 <= lim (stable, in place).
+__device__ inline void ring_compact(const float4* __restrict__ pts, uint16_t* __restrict__ ring, int& cnt,
+                                    float lim, float qx, float qy, float qz) {
     int keep = 0;
-#pragma unroll 4
-    for (int j = 0; j < NB; ++j) {
-        if (j < cnt) {
-            const uint16_t s = ring[j * kBrickThreads];
-            const float4 c = pts[s];
-            const float d = dist2<float>(qx, qy, qz, c.x, c.y, c.z);
-            if (d <= tau) {
-                ring[keep * kBrickThreads] = s;
-                ++keep;
-            }
-        }
+    for (int j = 0; __any(j < cnt); ++j) {
+        const uint16_t s = ring[(j < cnt ? j : 0) * kBrickThreads];
+        const float4 c = pts[s];
+        const float d = dist2<float>(qx, qy, qz, c.x, c.y, c.z);
+        const bool ok = (j < cnt) && (d <= lim);
+        ring[(ok ? keep : NB) * kBrickThreads] = s;
+        keep += ok ? 1 : 0;
     }
     cnt = keep;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(kBrickThreads) void brick_kernel(SearchArgs<float> a, int hcap) {
+// Fast-math force law for the brick path (1-ulp rcp/rsq; the wave kernel keeps the IEEE forms):
+// returns f(u) with u2 = d2/s^2.
+__device__ inline float force_fast(int kind, float beta, float u0sq, float gamma, float u2) {
+    const float d = u2 + beta;
+    if (kind == WTP_FORCE_STRONG_SPACING) return (1.f - u2) * __builtin_amdgcn_exp2f(-gamma * __builtin_amdgcn_logf(d));
+    const float inv = __builtin_amdgcn_rcpf(d * d);
+    if (kind == WTP_FORCE_INVERSE_DISTANCE) return inv;
+    if (kind == WTP_FORCE_SPACING_EQUILIBRIUM) return (1.f - u2) * inv;
+    const float f = (u0sq - u2) * inv;
+    return f > 0.f ? f : 0.f;
+}
+
+template <int MODE, int KT>
+__global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<float> a, int hcap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* pts = reinterpret_cast<float4*>(smem_raw);
     uint16_t* ring_all = reinterpret_cast<uint16_t*>(smem_raw + (size_t)hcap * sizeof(float4));
     BrickSmem* sm = reinterpret_cast<BrickSmem*>(smem_raw + (size_t)hcap * sizeof(float4) +
-                                                 (size_t)NB * kBrickThreads * sizeof(uint16_t));
+                                                 (size_t)(NB + 1) * kBrickThreads * sizeof(uint16_t));
     const int tid = threadIdx.x;
-    uint16_t* ring = ring_all + tid; // entry j at ring[j * kBrickThreads]
+    uint16_t* ring = ring_all + tid; // entry j at ring[j * kBrickThreads]; row NB is a dump row
 
     const Grid<float> g = *a.grid;
-    const int K = a.k;
+    const int K = KT > 0 ? KT : a.k;
     const bool skip_self = (MODE == 0) && !a.include_self;
     const float cap2 = (a.gamma_cap * g.c) * (a.gamma_cap * g.c);
     Acc acc = acc_empty();
+    // masked-off ring reads use row 0: make every slot ever read from it a valid LDS point index
+#pragma unroll 1
+    for (int j = 0; j <= NB; ++j) ring[j * kBrickThreads] = 0;
 
     // XCD-aware brick order: blocks sharing blockIdx % 8 share an L2; give each such group one
     // contiguous slab of bricks so halo re-reads of neighbouring bricks hit that L2.
@@ -143,7 +162,6 @@ __global__ __launch_bounds__(kBrickThreads) void brick_kernel(SearchArgs<float> 
             }
             sm->hglobal[tid] = gs;
         }
-        // block exclusive scan of my_cnt
         {
             int incl = my_cnt;
             const int lane = tid & 63, wave = tid >> 6;
@@ -213,7 +231,7 @@ __global__ __launch_bounds__(kBrickThreads) void brick_kernel(SearchArgs<float> 
             const int off = q - sm->own_pref[r];
             const int gslot = sm->hglobal[rbase] + off; // index in the sorted arrays
             if (!active) continue;
-            if (overflow) { // halo does not fit LDS: generic kernel takes the whole brick
+            if (overflow) { // halo does not fit LDS: the wave kernel takes the whole brick
                 const int pos = atomicAdd(a.fb_count, 1);
                 a.fb_list[pos] = gslot;
                 continue;
@@ -234,49 +252,71 @@ __global__ __launch_bounds__(kBrickThreads) void brick_kernel(SearchArgs<float> 
             int cnt = 0;
             bool giveup = false;
 
-#pragma unroll 1
-            for (int row = 0; row < 9; ++row) {
-                const int dz = row / 3 - 1, dy = row % 3 - 1;
-                const int base = ((hz + dz) * HY + (hy + dy)) * HX + (hx - 1);
-                const int s = sm->hstart[base], e = sm->hstart[base + 3];
-                for (int p = s; p < e; p += 4) {
-                    if (__any(cnt > NB - 4)) ring_prune(pts, ring, cnt, tau, qp.x, qp.y, qp.z, K);
-                    if (cnt > NB - 4) { // ring still full (mass tie): give up, go generic
-                        giveup = true;
-                        cnt = 0;
-                        tau = -1.f;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if (p + u < e) {
-                            const float4 c = pts[p + u];
-                            const float d = dist2<float>(qp.x, qp.y, qp.z, c.x, c.y, c.z);
-                            const bool take = (d <= tau) && !(skip_self && w_to_id(c.w) == qid);
-                            if (take) {
-                                ring[cnt * kBrickThreads] = (uint16_t)(p + u);
-                                ++cnt;
-                            }
+            // ---- scan / select loop: one instance of the network serves prunes and the final cut
+            int row = 0;
+            int p, e;
+            {
+                const int base = ((hz - 1) * HY + (hy - 1)) * HX + (hx - 1);
+                p = sm->hstart[base];
+                e = sm->hstart[base + 3];
+            }
+            uint32_t kth = 0, next = 0;
+            for (;;) {
+                bool pressure = false;
+                while (row < 9) {
+                    while (__any(p < e)) {
+                        if (__any(cnt > NB - 4)) {
+                            pressure = true;
+                            break;
                         }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int pi = p + u;
+                            const bool in = pi < e;
+                            const float4 c = pts[in ? pi : 0];
+                            const float d = dist2<float>(qp.x, qp.y, qp.z, c.x, c.y, c.z);
+                            const bool take = in && (d <= tau) && !(skip_self && w_to_id(c.w) == qid);
+                            ring[(take ? cnt : NB) * kBrickThreads] = (uint16_t)pi;
+                            cnt += take ? 1 : 0;
+                        }
+                        p += 4;
                     }
+                    if (pressure) break;
+                    ++row;
+                    if (row < 9) {
+                        const int dz = row / 3 - 1, dy = row % 3 - 1;
+                        const int base = ((hz + dz) * HY + (hy + dy)) * HX + (hx - 1);
+                        p = sm->hstart[base];
+                        e = sm->hstart[base + 3];
+                    }
+                }
+                ring_select<KT>(pts, ring, cnt, qp.x, qp.y, qp.z, K, kth, next);
+                if (!pressure) break;
+                if (cnt >= K) {
+                    const float t = u2f(kth);
+                    tau = t < tau ? t : tau;
+                }
+                ring_compact(pts, ring, cnt, tau, qp.x, qp.y, qp.z);
+                if (cnt > NB - 4) { // ring still full (mass tie): give up, the wave kernel takes it
+                    giveup = true;
+                    cnt = 0;
+                    tau = -1.f;
                 }
             }
 
-            bool fallback = (cnt < K) || giveup;
+            bool fallback = (cnt < K) || giveup || (kth == next); // tie exactly at the cut -> exact path
             if (MODE == 0) {
-                // canonical order: 64-bit key (d2 bits << 32 | id) over the survivors
-                uint64_t k[NB];
-#pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    if (j < cnt) {
-                        const float4 c = pts[ring[j * kBrickThreads]];
-                        const uint32_t d = f2u(dist2<float>(qp.x, qp.y, qp.z, c.x, c.y, c.z));
-                        k[j] = ((uint64_t)d << 32) | (uint32_t)w_to_id(c.w);
-                    } else {
-                        k[j] = ~0ull;
-                    }
-                }
-                WTP_SORTNET_64(k)
                 if (!fallback) {
+                    // survivors: exactly K entries with d2 <= cut; canonical order by 64-bit key
+                    ring_compact(pts, ring, cnt, u2f(kth), qp.x, qp.y, qp.z);
+                    uint64_t k[32];
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) {
+                        const float4 c = pts[ring[(j < cnt ? j : 0) * kBrickThreads]];
+                        const uint32_t d = f2u(dist2<float>(qp.x, qp.y, qp.z, c.x, c.y, c.z));
+                        k[j] = j < cnt ? (((uint64_t)d << 32) | (uint32_t)w_to_id(c.w)) : ~0ull;
+                    }
+                    WTP_SORTNET_32(k)
                     int32_t* orow = a.idx_out + (int64_t)qid * K;
                     float* drow = a.dist_out ? a.dist_out + (int64_t)qid * K : nullptr;
 #pragma unroll
@@ -288,36 +328,53 @@ __global__ __launch_bounds__(kBrickThreads) void brick_kernel(SearchArgs<float> 
                     }
                 }
             } else {
-                uint32_t kth, next;
-                ring_select(pts, ring, cnt, qp.x, qp.y, qp.z, K, kth, next);
-                fallback = fallback || (kth == next && K < NB); // tie exactly at the cut
                 if (!fallback) {
                     const float cut = u2f(kth);
                     const float s = a.spacing_pp ? a.spacing_pp[qid] : a.spacing_const;
+                    const float inv_s2 = 1.f / (s * s);
+                    const float u0sq = a.u0 * a.u0;
+                    // ClippedSpacingForce vanishes for u >= u0: neighbours beyond u0*s add nothing
+                    const float lim = (a.force_kind == WTP_FORCE_CLIPPED_SPACING && u0sq * (s * s) < cut)
+                                          ? u0sq * (s * s) : cut;
                     float Fx = 0.f, Fy = 0.f, Fz = 0.f;
-                    int32_t nid = -1;
+                    int32_t nid = 0x7FFFFFFF;
                     float nd2 = Lim<float>::inf();
-                    for (int j = 0; j < cnt; ++j) {
-                        const float4 c = pts[ring[j * kBrickThreads]];
-                        const float d = dist2<float>(qp.x, qp.y, qp.z, c.x, c.y, c.z);
+                    for (int j = 0; __any(j < cnt); ++j) {
+                        const float4 c = pts[ring[(j < cnt ? j : 0) * kBrickThreads]];
+                        const float dx = qp.x - c.x, dy = qp.y - c.y, dz = qp.z - c.z;
+                        const float d = (dx * dx + dy * dy) + dz * dz;
                         const int32_t cid = w_to_id(c.w);
-                        if (d <= cut && cid != qid) { // the kk nearest, self skipped by index (:271)
-                            if (lex_lt(d, cid, nd2, nid < 0 ? 0x7FFFFFFF : nid)) {
-                                nd2 = d;
-                                nid = cid;
+                        const bool in = (j < cnt) && (d <= cut) && (cid != qid); // the kk nearest, self skipped (:271)
+                        if (in && lex_lt(d, cid, nd2, nid)) {
+                            nd2 = d;
+                            nid = cid;
+                        }
+                        if (in && d <= lim) {
+                            const float f = force_fast(a.force_kind, a.beta, u0sq, a.gamma, d * inv_s2);
+                            if (d > 0.f) {
+                                const float coef = f * __builtin_amdgcn_rsqf(d);
+                                Fx += coef * dx;
+                                Fy += coef * dy;
+                                Fz += coef * dz;
+                            } else {
+                                float dir[3];
+                                fallback_dir<float>(qid, cid, g.dim, dir);
+                                Fx += f * dir[0];
+                                Fy += f * dir[1];
+                                Fz += f * dir[2];
                             }
-                            add_force<float>(a, g.dim, s, qp.x, qp.y, qp.z, qid, c.x, c.y, c.z, cid, d, Fx, Fy, Fz);
                         }
                     }
                     float4 o;
                     const float f = step_point<float>(a, s, qp.x, qp.y, qp.z, Fx, Fy, Fz, o.x, o.y, o.z);
                     o.w = qp.w;
-                    const float nd = nid < 0 ? Lim<float>::inf() : wsqrt(nd2);
+                    const bool has = nid != 0x7FFFFFFF;
+                    const float nd = has ? wsqrt(nd2) : Lim<float>::inf();
                     a.out[gslot] = o;
                     a.forces[gslot] = f;
                     a.nn_dist[gslot] = nd;
-                    a.nn_id[gslot] = nid;
-                    acc_point(acc, (double)f, (double)nd, (double)s, qid, nid);
+                    a.nn_id[gslot] = has ? nid : -1;
+                    acc_point(acc, (double)f, (double)nd, (double)s, qid, has ? nid : -1);
                 }
             }
             if (fallback) {
@@ -334,71 +391,66 @@ __global__ __launch_bounds__(kBrickThreads) void brick_kernel(SearchArgs<float> 
 }
 
 static size_t brick_smem_bytes(int hcap) {
-    return (size_t)hcap * sizeof(float4) + (size_t)NB * kBrickThreads * sizeof(uint16_t) + sizeof(BrickSmem);
+    return (size_t)hcap * sizeof(float4) + (size_t)(NB + 1) * kBrickThreads * sizeof(uint16_t) + sizeof(BrickSmem);
 }
 
 // LDS budget: 160 KiB per CU; hcap sized so two workgroups fit.
 static int pick_hcap() { return 2560; }
 
-template <int MODE> static int brick_grid(wtp_ctx* ctx, int hcap) {
-    int occ = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, brick_kernel<MODE>, kBrickThreads,
-                                                                brick_smem_bytes(hcap));
-    if (e != hipSuccess || occ < 1) occ = 1;
-    if (occ > 4) occ = 4;
+template <int MODE, int KT> static int brick_launch(wtp_ctx* ctx, SearchArgs<float>& a) {
+    const int hcap = pick_hcap();
+    static bool attr_set = false;
+    static int occ = 0;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)brick_kernel<MODE, KT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)brick_smem_bytes(hcap));
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, brick_kernel<MODE, KT>, kBrickThreads,
+                                                                    brick_smem_bytes(hcap));
+        if (e != hipSuccess || occ < 1) occ = 1;
+        if (occ > 4) occ = 4;
+        attr_set = true;
+    }
     int gsz = ctx->sm_count * occ;
     gsz -= gsz % 8;
-    return gsz < 8 ? 8 : gsz;
+    if (gsz < 8) gsz = 8;
+    hipLaunchKernelGGL((brick_kernel<MODE, KT>), dim3(gsz), dim3(kBrickThreads), brick_smem_bytes(hcap),
+                       ctx->stream, a, hcap);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
 }
 
 int brick_partials() { return 256 * 4 + 8; }
 
 template <> int launch_topology<float>(wtp_ctx* ctx, SearchArgs<float>& a) {
-    if (a.k > kFastKMax || ctx->force_generic) return launch_generic_topology<float>(ctx, a, true);
-    const int hcap = pick_hcap();
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)brick_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)brick_smem_bytes(hcap));
-        attr_set = true;
-    }
+    if (a.k > kFastKMax - 1 || ctx->force_generic) return launch_generic_topology<float>(ctx, a, true);
     a.gamma_cap = (float)ctx->gamma_cap;
     WTP_HIP(ctx, hipMemsetAsync(a.fb_count, 0, sizeof(int32_t), ctx->stream));
-    const int gsz = brick_grid<0>(ctx, hcap);
-    hipLaunchKernelGGL(brick_kernel<0>, dim3(gsz), dim3(kBrickThreads), brick_smem_bytes(hcap), ctx->stream, a, hcap);
-    WTP_HIP(ctx, hipGetLastError());
+    int rc = a.k == 21 ? brick_launch<0, 21>(ctx, a) : brick_launch<0, 0>(ctx, a);
+    if (rc) return rc;
     return launch_generic_topology<float>(ctx, a, false);
 }
 
 template <> int launch_topology<double>(wtp_ctx* ctx, SearchArgs<double>& a) {
-    return launch_generic_topology<double>(ctx, a, true); // fp64: exact generic path
+    return launch_generic_topology<double>(ctx, a, true); // fp64: exact wave-per-query path
 }
 
 template <> int launch_sweep<float>(wtp_ctx* ctx, SearchArgs<float>& a, bool fresh) {
     WTP_HIP(ctx, hipMemsetAsync(a.partials, 0, sizeof(Partial) * (size_t)a.n_partials, ctx->stream));
     WTP_HIP(ctx, hipMemsetAsync(a.fb_count, 0, sizeof(int32_t), ctx->stream));
-    if (!fresh || a.k > kFastKMax || ctx->force_generic) {
+    ctx->n_sweep_launches += 1;
+    if (!fresh || a.k > kFastKMax - 1 || ctx->force_generic) {
         const int sp = span_begin(ctx, 1);
         int rc = launch_generic_sweep<float>(ctx, a, true);
         span_end(ctx, sp);
         return rc;
     }
-    const int hcap = pick_hcap();
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)brick_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)brick_smem_bytes(hcap));
-        attr_set = true;
-    }
     a.gamma_cap = (float)ctx->gamma_cap;
-    const int gsz = brick_grid<1>(ctx, hcap);
     const int sp = span_begin(ctx, 1);
-    hipLaunchKernelGGL(brick_kernel<1>, dim3(gsz), dim3(kBrickThreads), brick_smem_bytes(hcap), ctx->stream, a, hcap);
+    int rc = a.k == 21 ? brick_launch<1, 21>(ctx, a) : brick_launch<1, 0>(ctx, a);
     span_end(ctx, sp);
-    ctx->n_sweep_launches += 1;
-    WTP_HIP(ctx, hipGetLastError());
+    if (rc) return rc;
     const int sp2 = span_begin(ctx, 2);
-    int rc = launch_generic_sweep<float>(ctx, a, false);
+    rc = launch_generic_sweep<float>(ctx, a, false);
     span_end(ctx, sp2);
     return rc;
 }
@@ -406,6 +458,7 @@ template <> int launch_sweep<float>(wtp_ctx* ctx, SearchArgs<float>& a, bool fre
 template <> int launch_sweep<double>(wtp_ctx* ctx, SearchArgs<double>& a, bool) {
     WTP_HIP(ctx, hipMemsetAsync(a.partials, 0, sizeof(Partial) * (size_t)a.n_partials, ctx->stream));
     WTP_HIP(ctx, hipMemsetAsync(a.fb_count, 0, sizeof(int32_t), ctx->stream));
+    ctx->n_sweep_launches += 1;
     const int sp = span_begin(ctx, 1);
     int rc = launch_generic_sweep<double>(ctx, a, true);
     span_end(ctx, sp);
