@@ -7,7 +7,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "libwtp.so")
+# WTP_LIB selects another build of the same sources (A/B experiments); default: csrc/libwtp.so
+SO_PATH = os.environ.get("WTP_LIB") or os.path.join(CSRC, "libwtp.so")
 
 WTP_OK, WTP_ERR_ARG, WTP_ERR_OOM, WTP_ERR_HIP, WTP_ERR_STATE, WTP_ERR_NO_DEVICE = range(6)
 WTP_F32, WTP_F64 = 0, 1

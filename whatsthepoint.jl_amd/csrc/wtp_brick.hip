@@ -29,6 +29,9 @@
 
 namespace wtp {
 
+#ifndef WTP_ABL
+#define WTP_ABL 0 // timing-only ablation builds (results wrong): 1 no force pass, 2 no select, 4 no scan
+#endif
 constexpr int NB = 64;          // per-lane candidate ring / sorting-network width
 constexpr int kFastKMax = 32;   // k >= this goes to the wave kernel
 constexpr int kOwnRows = BY * BZ;
@@ -49,6 +52,11 @@ struct BrickSmem {
         k[j] = hi_;                          \
     }
 
+// ring entries are byte offsets into the staged point area (< 64 KiB)
+__device__ inline float4 lds_pt(const float4* pts, uint32_t byte_off) {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(pts) + byte_off);
+}
+
 __device__ inline uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 __device__ inline float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 
@@ -63,7 +71,7 @@ __device__ inline void ring_select(const float4* __restrict__ pts, const uint16_
         if (__any(cnt > c8 * 8)) { // wave-uniform: skip chunks no lane has filled
 #pragma unroll
             for (int j = c8 * 8; j < c8 * 8 + 8; ++j) {
-                const float4 c = pts[ring[(j < cnt ? j : 0) * kBrickThreads]];
+                const float4 c = lds_pt(pts, ring[(j < cnt ? j : 0) * kBrickThreads]);
                 const uint32_t d = f2u(dist2<float>(qx, qy, qz, c.x, c.y, c.z));
                 k[j] = j < cnt ? d : 0x7F800000u;
             }
@@ -93,7 +101,7 @@ __device__ inline void ring_compact(const float4* __restrict__ pts, uint16_t* __
     int keep = 0;
     for (int j = 0; __any(j < cnt); ++j) {
         const uint16_t s = ring[(j < cnt ? j : 0) * kBrickThreads];
-        const float4 c = pts[s];
+        const float4 c = lds_pt(pts, s);
         const float d = dist2<float>(qx, qy, qz, c.x, c.y, c.z);
         const bool ok = (j < cnt) && (d <= lim);
         ring[(ok ? keep : NB) * kBrickThreads] = s;
@@ -118,8 +126,8 @@ template <int MODE, int KT>
 __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<float> a, int hcap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* pts = reinterpret_cast<float4*>(smem_raw);
-    uint16_t* ring_all = reinterpret_cast<uint16_t*>(smem_raw + (size_t)hcap * sizeof(float4));
-    BrickSmem* sm = reinterpret_cast<BrickSmem*>(smem_raw + (size_t)hcap * sizeof(float4) +
+    uint16_t* ring_all = reinterpret_cast<uint16_t*>(smem_raw + (size_t)hcap * sizeof(float4) + 64);
+    BrickSmem* sm = reinterpret_cast<BrickSmem*>(smem_raw + (size_t)hcap * sizeof(float4) + 64 +
                                                  (size_t)(NB + 1) * kBrickThreads * sizeof(uint16_t));
     const int tid = threadIdx.x;
     uint16_t* ring = ring_all + tid; // entry j at ring[j * kBrickThreads]; row NB is a dump row
@@ -249,48 +257,65 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
             const int hx = cx - ox, hy = cy - oy, hz = cz - oz;
             const float g2 = safe_radius2(g, qp.x, qp.y, qp.z, cx, cy, cz, 1);
             float tau = g2 < cap2 ? g2 : cap2;
+            const int32_t skip_id = skip_self ? qid : -1; // ids are >= 0
             int cnt = 0;
             bool giveup = false;
 
             // ---- scan / select loop: one instance of the network serves prunes and the final cut
+            // LDS byte addresses: points at [0, hcap*16), this lane's ring row j at ring_b + j*512
+            const uint32_t ring_b = (uint32_t)hcap * 16u + 64u + (uint32_t)tid * 2u;
+            const uint32_t dump_b = ring_b + (uint32_t)NB * (kBrickThreads * 2u);
+            const uint32_t full_b = ring_b + (uint32_t)(NB - 4) * (kBrickThreads * 2u);
+            uint32_t ra = ring_b; // next free ring entry
             int row = 0;
-            int p, e;
+            uint32_t pa, ea;      // current candidate run [pa, ea) as byte offsets into pts
             {
                 const int base = ((hz - 1) * HY + (hy - 1)) * HX + (hx - 1);
-                p = sm->hstart[base];
-                e = sm->hstart[base + 3];
+                pa = (uint32_t)sm->hstart[base] * 16u;
+                ea = (uint32_t)sm->hstart[base + 3] * 16u;
             }
             uint32_t kth = 0, next = 0;
             for (;;) {
                 bool pressure = false;
                 while (row < 9) {
-                    while (__any(p < e)) {
-                        if (__any(cnt > NB - 4)) {
+                    while (!(WTP_ABL & 4) && __any(pa < ea)) {
+                        if (__any(ra > full_b)) {
                             pressure = true;
                             break;
                         }
+                        // 4 candidates per step: reads first (one wait), then branch-free appends.
+                        // Reads past the run end stay inside the padded point area and are masked.
+                        float4 c[4];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
-                            const int pi = p + u;
-                            const bool in = pi < e;
-                            const float4 c = pts[in ? pi : 0];
-                            const float d = dist2<float>(qp.x, qp.y, qp.z, c.x, c.y, c.z);
-                            const bool take = in && (d <= tau) && !(skip_self && w_to_id(c.w) == qid);
-                            ring[(take ? cnt : NB) * kBrickThreads] = (uint16_t)pi;
-                            cnt += take ? 1 : 0;
+                            c[u] = *reinterpret_cast<const float4*>(smem_raw + pa + 16u * u);
                         }
-                        p += 4;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float d = dist2<float>(qp.x, qp.y, qp.z, c[u].x, c[u].y, c[u].z);
+                            // the id compare also keeps .w live: one ds_read_b128 per point, not b96
+                            const bool take = (pa + 16u * u < ea) && (d <= tau) && (w_to_id(c[u].w) != skip_id);
+                            *reinterpret_cast<uint16_t*>(smem_raw + (take ? ra : dump_b)) = (uint16_t)(pa + 16u * u);
+                            ra += take ? (kBrickThreads * 2u) : 0u;
+                        }
+                        pa += 64u;
                     }
                     if (pressure) break;
                     ++row;
                     if (row < 9) {
                         const int dz = row / 3 - 1, dy = row % 3 - 1;
                         const int base = ((hz + dz) * HY + (hy + dy)) * HX + (hx - 1);
-                        p = sm->hstart[base];
-                        e = sm->hstart[base + 3];
+                        pa = (uint32_t)sm->hstart[base] * 16u;
+                        ea = (uint32_t)sm->hstart[base + 3] * 16u;
                     }
                 }
-                ring_select<KT>(pts, ring, cnt, qp.x, qp.y, qp.z, K, kth, next);
+                cnt = (int)((ra - ring_b) / (kBrickThreads * 2u));
+                if (WTP_ABL & 2) {
+                    kth = f2u(tau);
+                    next = kth + 1;
+                } else {
+                    ring_select<KT>(pts, ring, cnt, qp.x, qp.y, qp.z, K, kth, next);
+                }
                 if (!pressure) break;
                 if (cnt >= K) {
                     const float t = u2f(kth);
@@ -302,9 +327,10 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
                     cnt = 0;
                     tau = -1.f;
                 }
+                ra = ring_b + (uint32_t)cnt * (kBrickThreads * 2u);
             }
 
-            bool fallback = (cnt < K) || giveup || (kth == next); // tie exactly at the cut -> exact path
+            bool fallback = !WTP_ABL && ((cnt < K) || giveup || (kth == next)); // tie exactly at the cut -> exact path
             if (MODE == 0) {
                 if (!fallback) {
                     // survivors: exactly K entries with d2 <= cut; canonical order by 64-bit key
@@ -312,7 +338,7 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
                     uint64_t k[32];
 #pragma unroll
                     for (int j = 0; j < 32; ++j) {
-                        const float4 c = pts[ring[(j < cnt ? j : 0) * kBrickThreads]];
+                        const float4 c = lds_pt(pts, ring[(j < cnt ? j : 0) * kBrickThreads]);
                         const uint32_t d = f2u(dist2<float>(qp.x, qp.y, qp.z, c.x, c.y, c.z));
                         k[j] = j < cnt ? (((uint64_t)d << 32) | (uint32_t)w_to_id(c.w)) : ~0ull;
                     }
@@ -339,29 +365,39 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
                     float Fx = 0.f, Fy = 0.f, Fz = 0.f;
                     int32_t nid = 0x7FFFFFFF;
                     float nd2 = Lim<float>::inf();
-                    for (int j = 0; __any(j < cnt); ++j) {
-                        const float4 c = pts[ring[(j < cnt ? j : 0) * kBrickThreads]];
-                        const float dx = qp.x - c.x, dy = qp.y - c.y, dz = qp.z - c.z;
-                        const float d = (dx * dx + dy * dy) + dz * dz;
-                        const int32_t cid = w_to_id(c.w);
-                        const bool in = (j < cnt) && (d <= cut) && (cid != qid); // the kk nearest, self skipped (:271)
-                        if (in && lex_lt(d, cid, nd2, nid)) {
-                            nd2 = d;
-                            nid = cid;
-                        }
-                        if (in && d <= lim) {
+                    // 4 ring entries per step: offsets, then points, then branch-free math (the LDS
+                    // round trips are the cost here, so they are issued together)
+                    for (int j0 = 0; !(WTP_ABL & 1) && __any(j0 < cnt); j0 += 4) {
+                        uint16_t off[4];
+                        float4 c[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) off[u] = ring[((j0 + u) < cnt ? (j0 + u) : 0) * kBrickThreads];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) c[u] = lds_pt(pts, off[u]);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float dx = qp.x - c[u].x, dy = qp.y - c[u].y, dz = qp.z - c[u].z;
+                            const float d = (dx * dx + dy * dy) + dz * dz;
+                            const int32_t cid = w_to_id(c[u].w);
+                            // the kk nearest, self skipped by index (src/repel.jl:271)
+                            const bool in = ((j0 + u) < cnt) && (d <= cut) && (cid != qid);
+                            const bool nearer = in && lex_lt(d, cid, nd2, nid);
+                            nd2 = nearer ? d : nd2;
+                            nid = nearer ? cid : nid;
+                            const bool act = in && (d <= lim);
                             const float f = force_fast(a.force_kind, a.beta, u0sq, a.gamma, d * inv_s2);
-                            if (d > 0.f) {
-                                const float coef = f * __builtin_amdgcn_rsqf(d);
-                                Fx += coef * dx;
-                                Fy += coef * dy;
-                                Fz += coef * dz;
-                            } else {
-                                float dir[3];
-                                fallback_dir<float>(qid, cid, g.dim, dir);
-                                Fx += f * dir[0];
-                                Fy += f * dir[1];
-                                Fz += f * dir[2];
+                            const float coef = (act && d > 0.f) ? f * __builtin_amdgcn_rsqf(d) : 0.f;
+                            Fx += coef * dx;
+                            Fy += coef * dy;
+                            Fz += coef * dz;
+                            if (__any(act && !(d > 0.f))) { // coincident points: rare
+                                if (act && !(d > 0.f)) {
+                                    float dir[3];
+                                    fallback_dir<float>(qid, cid, g.dim, dir);
+                                    Fx += f * dir[0];
+                                    Fy += f * dir[1];
+                                    Fz += f * dir[2];
+                                }
                             }
                         }
                     }
@@ -391,7 +427,7 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
 }
 
 static size_t brick_smem_bytes(int hcap) {
-    return (size_t)hcap * sizeof(float4) + (size_t)(NB + 1) * kBrickThreads * sizeof(uint16_t) + sizeof(BrickSmem);
+    return (size_t)hcap * sizeof(float4) + 64 + (size_t)(NB + 1) * kBrickThreads * sizeof(uint16_t) + sizeof(BrickSmem);
 }
 
 // LDS budget: 160 KiB per CU; hcap sized so two workgroups fit.
