@@ -80,17 +80,24 @@ __global__ void bbox_kernel(const Pt<T>* __restrict__ pts, int64_t n, T* __restr
 template <typename T>
 __global__ void grid_setup_kernel(const T* __restrict__ part, int nparts, Grid<T>* __restrict__ g,
                                   int64_t npts, int dim, double rho_k, double radius, int cell_cap) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // one wave: lanes stride over the per-block partials, shuffle-reduce, lane 0 does the setup
     double mn[3], mx[3];
     for (int a = 0; a < 3; ++a) {
-        T lo = part[a], hi = part[3 + a];
-        for (int b = 1; b < nparts; ++b) {
+        T lo = Lim<T>::inf(), hi = -Lim<T>::inf();
+        for (int b = threadIdx.x; b < nparts; b += 64) {
             lo = part[b * 6 + a] < lo ? part[b * 6 + a] : lo;
             hi = part[b * 6 + 3 + a] > hi ? part[b * 6 + 3 + a] : hi;
+        }
+        for (int d = 32; d >= 1; d >>= 1) {
+            T o = __shfl_down(lo, d, 64);
+            lo = o < lo ? o : lo;
+            o = __shfl_down(hi, d, 64);
+            hi = o > hi ? o : hi;
         }
         mn[a] = (double)lo;
         mx[a] = (double)hi;
     }
+    if (threadIdx.x != 0) return;
     double ext[3], emax = 0;
     for (int a = 0; a < 3; ++a) {
         ext[a] = a < dim ? mx[a] - mn[a] : 0.0;
@@ -148,14 +155,31 @@ template <typename T>
 __global__ void cell_rank_kernel(const Pt<T>* __restrict__ pts, int64_t n, const Grid<T>* __restrict__ gp,
                                  int32_t* __restrict__ cell_cnt, int2* __restrict__ cell_rank) {
     const Grid<T> g = *gp;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) {
-        Pt<T> p = pts[i];
-        int cx = cell_coord(g, p.x, 0), cy = cell_coord(g, p.y, 1), cz = cell_coord(g, p.z, 2);
-        int cell = (cz * g.n[1] + cy) * g.n[0] + cx;
-        int r = atomicAdd(&cell_cnt[cell], 1);
-        cell_rank[i] = make_int2(cell, r);
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    // On rebuilds the input is the previous sorted order, so consecutive lanes mostly share a
+    // cell: one atomic per run of equal cells instead of one per point (~8x fewer atomics).
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < n; base += stride) {
+        const int64_t i = base + threadIdx.x;
+        const bool valid = i < n;
+        int cell = -1;
+        if (valid) {
+            Pt<T> p = pts[i];
+            int cx = cell_coord(g, p.x, 0), cy = cell_coord(g, p.y, 1), cz = cell_coord(g, p.z, 2);
+            cell = (cz * g.n[1] + cy) * g.n[0] + cx;
+        }
+        const int prev = __shfl_up(cell, 1, 64);
+        const bool head = (lane == 0) || (prev != cell);
+        const unsigned long long heads = __ballot(head);
+        // my run starts at the highest head bit at or below my lane, ends before the next head
+        const unsigned long long below = heads & ((2ull << lane) - 1ull);
+        const int start = 63 - __builtin_clzll(below);
+        const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+        const int len_to_end = above ? __builtin_ctzll(above) + 1 : 64 - lane; // valid for the head lane
+        int r0 = 0;
+        if (head && valid) r0 = atomicAdd(&cell_cnt[cell], len_to_end);
+        r0 = __shfl(r0, start, 64);
+        if (valid) cell_rank[i] = make_int2(cell, r0 + (lane - start));
     }
 }
 
@@ -271,25 +295,63 @@ __global__ void scatter_kernel(const Pt<T>* __restrict__ pts, int64_t n, const i
 // kCanonMax keep arrival order (results stay exact; only fp summation order may vary).
 static constexpr int kCanonMax = 96;
 
+template <typename T> struct CanonCap;
+template <> struct CanonCap<float> { static constexpr int pts = 3072; };   // 48 KiB of LDS
+template <> struct CanonCap<double> { static constexpr int pts = 1536; };
+
+// A workgroup owns kThreads consecutive cells = one contiguous run of the sorted array.  The run
+// is staged into LDS with coalesced loads, each thread insertion-sorts its own cell by id there,
+// and the run is written back coalesced.  Runs too large for LDS sort in place in global memory.
 template <typename T>
-__global__ void canon_kernel(Pt<T>* __restrict__ pts, const int32_t* __restrict__ cell_start,
-                             const Grid<T>* __restrict__ gp) {
-    int ncells = gp->ncells;
-    int cell = blockIdx.x * blockDim.x + threadIdx.x;
-    int stride = gridDim.x * blockDim.x;
-    for (; cell < ncells; cell += stride) {
-        int s = cell_start[cell], e = cell_start[cell + 1];
-        int m = e - s;
-        if (m < 2 || m > kCanonMax) continue;
-        for (int i = 1; i < m; ++i) {
-            Pt<T> key = pts[s + i];
-            int kid = w_to_id(key.w);
-            int j = i - 1;
-            while (j >= 0 && w_to_id(pts[s + j].w) > kid) {
-                pts[s + j + 1] = pts[s + j];
-                --j;
+__global__ __launch_bounds__(kThreads) void canon_kernel(Pt<T>* __restrict__ pts,
+                                                         const int32_t* __restrict__ cell_start,
+                                                         const Grid<T>* __restrict__ gp) {
+    __shared__ Pt<T> buf[CanonCap<T>::pts];
+    const int ncells = gp->ncells;
+    for (int c0 = blockIdx.x * kThreads; c0 < ncells; c0 += gridDim.x * kThreads) {
+        const int c1 = c0 + kThreads < ncells ? c0 + kThreads : ncells;
+        const int p0 = cell_start[c0], p1 = cell_start[c1];
+        const int cell = c0 + threadIdx.x;
+        int s = 0, m = 0;
+        if (cell < c1) {
+            s = cell_start[cell];
+            m = cell_start[cell + 1] - s;
+        }
+        const bool in_lds = (p1 - p0) <= CanonCap<T>::pts;
+        __syncthreads();
+        if (in_lds) {
+            for (int i = p0 + threadIdx.x; i < p1; i += kThreads) buf[i - p0] = pts[i];
+            __syncthreads();
+        }
+        if (m >= 2 && m <= kCanonMax) {
+            if (in_lds) {
+                Pt<T>* b = buf + (s - p0);
+                for (int i = 1; i < m; ++i) {
+                    const Pt<T> key = b[i];
+                    const int kid = w_to_id(key.w);
+                    int j = i - 1;
+                    while (j >= 0 && w_to_id(b[j].w) > kid) {
+                        b[j + 1] = b[j];
+                        --j;
+                    }
+                    b[j + 1] = key;
+                }
+            } else {
+                for (int i = 1; i < m; ++i) {
+                    const Pt<T> key = pts[s + i];
+                    const int kid = w_to_id(key.w);
+                    int j = i - 1;
+                    while (j >= 0 && w_to_id(pts[s + j].w) > kid) {
+                        pts[s + j + 1] = pts[s + j];
+                        --j;
+                    }
+                    pts[s + j + 1] = key;
+                }
             }
-            pts[s + j + 1] = key;
+        }
+        if (in_lds) {
+            __syncthreads();
+            for (int i = p0 + threadIdx.x; i < p1; i += kThreads) pts[i] = buf[i - p0];
         }
     }
 }
