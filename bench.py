@@ -45,6 +45,13 @@ def cpu_baseline(points: int, iters: int):
                 sample=f"{iters} repel iterations on {points} uniform fp32 points (kd-tree + OpenMP oracle, {dt:.1f} s)")
 
 
+def ctx_rho() -> float:
+    try:
+        return float(os.environ.get("WTP_RHO", "8"))
+    except ValueError:
+        return 8.0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,7 +98,14 @@ def main():
     else:
         from whatsthepoint_jl_amd import sharded
 
-        drv = sharded.ShardedRelax(ctx, dist, n_total, s, force, k, s / 2000, s / 20, seed=wtp_amd.synth.SEED)
+        def gen(first, n):
+            t = torch.empty((n, 3), dtype=torch.float32, device="cuda")
+            ctx.gen_uniform_dev(wtp_amd.synth.SEED, first, n, 3, np.float32, t.data_ptr())
+            return t
+
+        own_xyz, own_gid, cuts = sharded.uniform_shard(gen, rank, world, n_total, wtp_amd.synth.SEED, "cuda")
+        drv = sharded.ShardedRelax(sharded.GpuEngine(ctx, s, force, k, s / 2000, s / 20), dist, own_xyz, own_gid, cuts,
+                                   sharded.ghost_width(n_total, k, ctx_rho()))
 
         def run(iters):
             drv.run(iters)

@@ -153,6 +153,8 @@ int wtp_relax_run(wtp_ctx* ctx, int n_iters, int rebuild_every, double* conv_out
 
 /* Current movable points, (n - n_fixed) x dim of dtype, snapshot order. */
 int wtp_relax_get(wtp_ctx* ctx, void* xyz_out);
+/* Same into device memory on the context's GPU (sharded driver: no host round trip). */
+int wtp_relax_get_dev(wtp_ctx* ctx, void* d_xyz_out);
 /* Per-point outputs of the last sweep, each n - n_fixed long (any may be NULL):
  * forces (|F|*s), nn_dist (dtype), nn_id (int32 snapshot-global, -1 if none). */
 int wtp_relax_get_point_data(wtp_ctx* ctx, void* forces_out, void* nn_dist_out,

@@ -58,6 +58,7 @@ SIGNATURES = {
     "wtp_relax_step": (_i, [_vp, _i, C.POINTER(StepStats)]),
     "wtp_relax_run": (_i, [_vp, _i, _i, _vp, C.POINTER(StepStats)]),
     "wtp_relax_get": (_i, [_vp, _vp]),
+    "wtp_relax_get_dev": (_i, [_vp, _vp]),
     "wtp_relax_get_point_data": (_i, [_vp, _vp, _vp, _vp]),
     "wtp_relax_set": (_i, [_vp, _i64, _vp]),
     "wtp_relax_revert": (_i, [_vp]),

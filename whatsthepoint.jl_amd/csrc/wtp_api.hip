@@ -581,6 +581,22 @@ WTP_API int wtp_relax_get(wtp_ctx* ctx, void* xyz_out) {
     return sync(ctx);
 }
 
+WTP_API int wtp_relax_get_dev(wtp_ctx* ctx, void* d_xyz_out) {
+    if (!ctx) return WTP_ERR_ARG;
+    RelaxState& r = ctx->relax;
+    if (!r.active) return fail(ctx, WTP_ERR_STATE, "wtp_relax_get_dev before wtp_relax_init");
+    if (!d_xyz_out) return fail(ctx, WTP_ERR_ARG, "xyz_out is NULL");
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    if (r.n - r.n_fixed == 0) return WTP_OK;
+    int rc;
+    if (r.dtype == WTP_F32)
+        rc = launch_unpermute<float>(ctx, (const float4*)ctx->pts[r.bufP].p, r.n, r.n_fixed, r.dim, (float*)d_xyz_out);
+    else
+        rc = launch_unpermute<double>(ctx, (const double4*)ctx->pts[r.bufP].p, r.n, r.n_fixed, r.dim, (double*)d_xyz_out);
+    if (rc) return rc;
+    return sync(ctx);
+}
+
 WTP_API int wtp_relax_get_point_data(wtp_ctx* ctx, void* forces_out, void* nn_dist_out, int32_t* nn_id_out) {
     if (!ctx) return WTP_ERR_ARG;
     RelaxState& r = ctx->relax;

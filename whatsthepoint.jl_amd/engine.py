@@ -184,6 +184,10 @@ class RelaxSession:
         L.check(self.ctx._h, self._lib.wtp_relax_get(self.ctx._h, _vp(out)))
         return out
 
+    def positions_dev(self, d_out_ptr: int):
+        """Movable points into device memory ((n - n_fixed) x dim of dtype)."""
+        L.check(self.ctx._h, self._lib.wtp_relax_get_dev(self.ctx._h, C.c_void_p(d_out_ptr)))
+
     def point_data(self):
         m = self.n - self.n_fixed
         forces = np.empty(m, dtype=self.dtype)

@@ -1,0 +1,216 @@
+"""Sharded repel sweep: one process per GPU, spatial slabs + ghost-layer exchange per iteration.
+
+SURVEY.md §8e.  The reference has no distribution at all (one address space, one kd-tree); this
+is the build's own decomposition of the same Jacobi sweep (src/repel.jl:254-292):
+
+  partition   the bounding box is cut along z into `world` slabs (an orthtree cut along one axis;
+              for the uniform benchmark cloud the cuts are equidistant, otherwise z-quantiles).
+  ghosts      each rank needs, read-only, every foreign point within `w` of its slab, where
+              w >= the largest radius any local exactness certificate can use
+              (ghost_cells * hash cell edge).  Ghosts enter the local snapshot as its FIXED head
+              (n_fixed = n_ghost): searched, never moved, never counted in the reductions.
+  iteration   migrate points that left the slab -> exchange ghosts (point-to-point with the two
+              neighbours: RCCL over xGMI on GPUs, gloo in the CPU tests) -> local hash + sweep of
+              the owned points (libwtp) -> all-reduce of {max force, sum u, sum u^2, n} .
+Global ids travel with the points, so results are independent of the decomposition: a 1-rank
+and an N-rank run produce the same per-point positions (tests/test_sharded_gloo.py).
+
+The exchange and bookkeeping are torch tensor ops (plumbing); the sweep itself is the C-ABI
+library.  `engine` abstracts that one call so the N>1 logic is testable on CPU ranks.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+
+class GpuEngine:
+    """Local sweep through libwtp on this rank's GPU (device-resident in and out)."""
+
+    def __init__(self, ctx, spacing, force, k, alpha_lo, alpha_max):
+        self.ctx, self.spacing, self.force, self.k = ctx, spacing, force, k
+        self.alpha_lo, self.alpha_max = alpha_lo, alpha_max
+
+    def sweep(self, local_xyz: torch.Tensor, n_ghost: int):
+        n = local_xyz.shape[0]
+        out = torch.empty((n - n_ghost, 3), dtype=local_xyz.dtype, device=local_xyz.device)
+        sess = self.ctx.relax(None, n_ghost, self.spacing, self.force, self.k, self.alpha_lo, self.alpha_max,
+                              device_ptr=(local_xyz.data_ptr(), n, 3, np.float32))
+        try:
+            st = sess.step(True)
+            sess.positions_dev(out.data_ptr())
+        finally:
+            sess.close()
+        return out, st
+
+
+def slab_of(z: torch.Tensor, cuts: torch.Tensor) -> torch.Tensor:
+    """Owner rank of each z: cuts has world-1 ascending interior planes."""
+    return torch.bucketize(z.contiguous(), cuts, right=True)
+
+
+class ShardedRelax:
+    """Owns this rank's points (positions + global ids) and runs sharded repel iterations."""
+
+    def __init__(self, engine, dist, owned_xyz: torch.Tensor, owned_gid: torch.Tensor, cuts, ghost_width: float,
+                 rank: int = None, world: int = None, comm_device=None):
+        """comm_device: where collective payloads live — the points' own device for RCCL ("nccl"
+        backend), "cpu" to stage through host memory when the backend is gloo (rehearsals with
+        several ranks on one GPU)."""
+        self.engine, self.dist = engine, dist
+        self.rank = dist.get_rank() if rank is None else rank
+        self.world = dist.get_world_size() if world is None else world
+        self.xyz, self.gid = owned_xyz, owned_gid
+        self.dev = owned_xyz.device
+        self.cdev = torch.device(comm_device) if comm_device is not None else self.dev
+        self.cuts = torch.as_tensor(cuts, dtype=owned_xyz.dtype, device=self.dev).reshape(-1)
+        self.w = float(ghost_width)
+        self.last_local_points = int(owned_xyz.shape[0])
+        self.history = []
+
+    # ---- point-to-point exchange with the two slab neighbours ------------------------------------
+    def _exchange(self, to_lo: torch.Tensor, to_hi: torch.Tensor):
+        """Send `to_lo` to rank-1 and `to_hi` to rank+1; return (from_lo, from_hi).  Payload rows
+        are [x, y, z, gid_lo_bits, gid_hi_bits] as float32-compatible words packed in an int32 view."""
+        d, r, W = self.dist, self.rank, self.world
+        lo, hi = r - 1, r + 1
+        to_lo, to_hi = to_lo.to(self.cdev), to_hi.to(self.cdev)
+        cnt_send = torch.tensor([to_lo.shape[0], to_hi.shape[0]], dtype=torch.int64, device=self.cdev)
+        cnt_all = [torch.zeros(2, dtype=torch.int64, device=self.cdev) for _ in range(W)]
+        d.all_gather(cnt_all, cnt_send)
+        n_from_lo = int(cnt_all[lo][1].item()) if lo >= 0 else 0
+        n_from_hi = int(cnt_all[hi][0].item()) if hi < W else 0
+        cols = to_lo.shape[1]
+        from_lo = torch.empty((n_from_lo, cols), dtype=to_lo.dtype, device=self.cdev)
+        from_hi = torch.empty((n_from_hi, cols), dtype=to_lo.dtype, device=self.cdev)
+        ops = []
+        if lo >= 0:
+            if to_lo.shape[0]:
+                ops.append(d.P2POp(d.isend, to_lo.contiguous(), lo))
+            if n_from_lo:
+                ops.append(d.P2POp(d.irecv, from_lo, lo))
+        if hi < W:
+            if to_hi.shape[0]:
+                ops.append(d.P2POp(d.isend, to_hi.contiguous(), hi))
+            if n_from_hi:
+                ops.append(d.P2POp(d.irecv, from_hi, hi))
+        if ops:
+            for req in d.batch_isend_irecv(ops):
+                req.wait()
+        return from_lo.to(self.dev), from_hi.to(self.dev)
+
+    def _pack(self, mask):
+        gid = self.gid[mask]
+        words = torch.stack([(gid & 0xFFFFFFFF).to(torch.int64), (gid >> 32).to(torch.int64)], 1).to(torch.int32)
+        return torch.cat([self.xyz[mask].view(torch.int32), words], 1)
+
+    @staticmethod
+    def _unpack(buf, dtype):
+        xyz = buf[:, :3].contiguous().view(dtype)
+        gid = (buf[:, 3].to(torch.int64) & 0xFFFFFFFF) | (buf[:, 4].to(torch.int64) << 32)
+        return xyz, gid
+
+    def _bounds(self):
+        lo = float(self.cuts[self.rank - 1]) if self.rank > 0 else -math.inf
+        hi = float(self.cuts[self.rank]) if self.rank < self.world - 1 else math.inf
+        return lo, hi
+
+    # ---- one iteration ---------------------------------------------------------------------------------
+    def step(self):
+        lo, hi = self._bounds()
+        z = self.xyz[:, 2]
+        # 1. migration: points that crossed a cut move to the neighbour slab (|disp| <= s << slab)
+        go_lo, go_hi = z < lo, z >= hi
+        if self.world > 1:
+            keep = ~(go_lo | go_hi)
+            from_lo, from_hi = self._exchange(self._pack(go_lo), self._pack(go_hi))
+            parts_x, parts_g = [self.xyz[keep]], [self.gid[keep]]
+            for b in (from_lo, from_hi):
+                if b.shape[0]:
+                    x, g = self._unpack(b, self.xyz.dtype)
+                    parts_x.append(x)
+                    parts_g.append(g)
+            self.xyz, self.gid = torch.cat(parts_x), torch.cat(parts_g)
+            z = self.xyz[:, 2]
+        # 2. ghost layer: foreign points within w of my slab
+        if self.world > 1:
+            g_lo, g_hi = self._exchange(self._pack(z < lo + self.w), self._pack(z >= hi - self.w))
+            gx = [self._unpack(b, self.xyz.dtype)[0] for b in (g_lo, g_hi) if b.shape[0]]
+            ghosts = torch.cat(gx) if gx else self.xyz[:0]
+        else:
+            ghosts = self.xyz[:0]
+        n_ghost = int(ghosts.shape[0])
+        # 3. local snapshot = [ghosts (fixed head) ; owned (movable tail)] -> sweep
+        local = torch.cat([ghosts, self.xyz]).contiguous()
+        self.last_local_points = int(local.shape[0])
+        new_xyz, st = self.engine.sweep(local, n_ghost)
+        self.xyz = new_xyz
+        # 4. global reductions of the stop-rule scalars (src/repel.jl:293,374-386)
+        red = torch.tensor([st["sum_u"], st["sum_u2"], float(st["n_move"])], dtype=torch.float64, device=self.cdev)
+        mx = torch.tensor([st["max_force"]], dtype=torch.float64, device=self.cdev)
+        if self.world > 1:
+            self.dist.all_reduce(red, op=self.dist.ReduceOp.SUM)
+            self.dist.all_reduce(mx, op=self.dist.ReduceOp.MAX)
+        out = dict(max_force=float(mx[0]), sum_u=float(red[0]), sum_u2=float(red[1]), n_move=int(red[2]),
+                   n_ghost=n_ghost, n_owned=int(self.xyz.shape[0]), n_fallback=int(st.get("n_fallback", 0)))
+        self.history.append(out)
+        return out
+
+    def run(self, iters: int):
+        last = None
+        for _ in range(iters):
+            last = self.step()
+        return last
+
+    def points_per_launch(self) -> int:
+        return self.last_local_points
+
+    def gather_global(self, n_total: int):
+        """All points on every rank, ordered by global id (tests / read-back)."""
+        buf = self._pack(torch.ones(self.xyz.shape[0], dtype=torch.bool, device=self.dev)).to(self.cdev)
+        cnt = torch.tensor([buf.shape[0]], dtype=torch.int64, device=self.cdev)
+        cnts = [torch.zeros(1, dtype=torch.int64, device=self.cdev) for _ in range(self.world)]
+        if self.world > 1:
+            self.dist.all_gather(cnts, cnt)
+        else:
+            cnts = [cnt]
+        mx = int(max(int(c.item()) for c in cnts))
+        pad = torch.zeros((mx, buf.shape[1]), dtype=buf.dtype, device=self.cdev)
+        pad[: buf.shape[0]] = buf
+        allb = [torch.zeros_like(pad) for _ in range(self.world)]
+        if self.world > 1:
+            self.dist.all_gather(allb, pad)
+        else:
+            allb = [pad]
+        out = torch.empty((n_total, 3), dtype=self.xyz.dtype, device=self.cdev)
+        for c, b in zip(cnts, allb):
+            x, g = self._unpack(b[: int(c.item())], self.xyz.dtype)
+            out[g] = x
+        return out
+
+
+def uniform_shard(ctx_gen, rank: int, world: int, n_total: int, seed: int, device, chunk: int = 8_000_000):
+    """This rank's z-slab of the synthetic uniform cloud: the global stream is
+    generated in chunks and filtered, so global ids equal the single-GPU run's point indices.
+    ctx_gen(first, n) -> (n, 3) float32 tensor on `device`."""
+    lo, hi = rank / world, (rank + 1) / world
+    xs, gs = [], []
+    for first in range(0, n_total, chunk):
+        n = min(chunk, n_total - first)
+        x = ctx_gen(first, n)
+        z = x[:, 2]
+        m = (z >= lo) & (z < hi) if rank < world - 1 else (z >= lo)
+        xs.append(x[m])
+        gs.append(torch.nonzero(m).reshape(-1).to(torch.int64) + first)
+    cuts = [(r + 1) / world for r in range(world - 1)]
+    return torch.cat(xs).contiguous(), torch.cat(gs).contiguous(), cuts
+
+
+def ghost_width(n_total: int, k: int, rho: float = 8.0, ghost_cells: float = 3.0, dim: int = 3) -> float:
+    """ghost_cells x the hash cell edge libwtp will choose for this density (csrc/wtp_hash.hip
+    build_hash: c = (rho_k / density)^(1/dim), rho_k = 0.381 k rho/8).  3 cells cover the fast
+    path's certificate radius (1.08 c) and the wave kernel's first ring (2.5 c)."""
+    rho_k = (0.381 if dim == 3 else 0.436) * k * (rho / 8.0)
+    return ghost_cells * (max(rho_k, 1.0) / n_total) ** (1.0 / dim)
