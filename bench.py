@@ -55,12 +55,12 @@ def ctx_rho() -> float:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=10_000_000, help="points per GPU (weak scaling)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--cpu-points", type=int, default=1_000_000)
-    ap.add_argument("--cpu-iters", type=int, default=4)
+    ap.add_argument("--cpu-points", type=int, default=4_000_000)
+    ap.add_argument("--cpu-iters", type=int, default=6)
     args = ap.parse_args()
 
     import numpy as np
@@ -172,6 +172,14 @@ def main():
                 "fallback_reduce": round(tm["other_ms"] / args.steps, 4),
             },
         }
+        # HBM bytes per launch come from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 on
+        # gfx950 + WRITE_SIZE), scaled to this launch's point count; counters cannot be read live.
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            out["roofline"]["traffic"] = round(tj["traffic_bytes_per_launch"] * pts_per_launch / tj["points_per_launch"])
+            out["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
+            out["roofline"]["algorithmic_bytes"] = round(B_ALG_SWEEP * pts_per_launch)
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.cpu_points, args.cpu_iters)
         print(json.dumps(out), flush=True)

@@ -1,0 +1,95 @@
+"""The reference-shaped host API (PointCloud / set_topology / repel) end to end on the GPU,
+checked with the assertions the reference's own tests make (test/topology.jl, test/repel.jl)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cloud(wtp, nb=400, nv=2000, dtype=np.float64, seed=3):
+    rng = np.random.default_rng(seed)
+    # boundary: points on the faces of the unit cube; volume: uniform inside
+    b = rng.random((nb, 3))
+    f = rng.integers(0, 6, nb)
+    b[np.arange(nb), f % 3] = (f // 3).astype(float)
+    v = 0.05 + 0.9 * rng.random((nv, 3))
+    return wtp.PointCloud(wtp.PointBoundary(b.astype(dtype)), wtp.PointVolume(v.astype(dtype)))
+
+
+def test_set_topology_knn_and_radius(ctx, O, wtp):
+    cloud = _cloud(wtp)
+    c2 = wtp.set_topology(cloud, wtp.KNNTopology, 5, ctx=ctx)
+    assert wtp.hastopology(c2) and not wtp.hastopology(cloud)          # functional: new cloud
+    nb = wtp.neighbors(c2)
+    assert nb.shape == (len(cloud), 5)
+    assert not (nb == np.arange(len(cloud))[:, None]).any()             # test/topology.jl:40
+    assert np.array_equal(nb, O.knn(wtp.points(cloud), 5, False, "kdtree", want_dist=False))
+    assert len(wtp.neighbors(c2, 1)) == 5
+    wtp.rebuild_topology(c2, ctx=ctx)
+    assert c2.topology.k == 5 and wtp.neighbors(c2).shape == (len(cloud), 5)
+    c3 = wtp.set_topology(cloud, wtp.RadiusTopology, 0.12, ctx=ctx)
+    assert c3.topology.radius == 0.12
+    off, idx = O.radius(wtp.points(cloud), 0.12)
+    for i in (0, 17, len(cloud) - 1):
+        assert np.array_equal(wtp.neighbors(c3, i), idx[off[i]:off[i + 1]])
+    # surface- and volume-level topologies index locally (test/topology.jl:165-263)
+    v2 = cloud.volume.set_topology(wtp.KNNTopology, 4, ctx=ctx)
+    assert v2.neighbors().max() < len(cloud.volume)
+
+
+def test_search_and_searchdists(ctx, wtp):
+    N = 20
+    th = np.linspace(0, 2 * np.pi, N + 1)[:-1]
+    cloud = wtp.PointCloud(wtp.PointBoundary(np.stack([np.cos(th), np.sin(th)], 1)))
+    m = wtp.KNearestSearch(cloud, 3)
+    nb = wtp.search(cloud, m, ctx=ctx)
+    assert nb.shape == (N, 3) and (nb[:, 0] == np.arange(N)).all()      # test/neighbors.jl:54-56
+    idx, d = wtp.searchdists(cloud, m, ctx=ctx)
+    assert (d >= 0).all() and np.allclose(d[:, 0], 0, atol=1e-10) and (np.diff(d, axis=1) >= 0).all()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_repel_stop_rules_and_types(ctx, wtp, dtype):
+    cloud = _cloud(wtp, dtype=dtype)
+    n_vol = len(cloud.volume)
+    s = 0.06
+    conv = []
+    new = wtp.repel(cloud, wtp.ConstantSpacing(s), max_iters=3, convergence=conv, ctx=ctx)
+    assert len(conv) == 3 and all(np.isfinite(conv)) and min(conv) >= 0  # test/float32_pipeline.jl:49-52
+    assert new.volume.points().dtype == dtype and isinstance(new.topology, wtp.NoTopology)
+    assert len(new.volume) == n_vol and np.array_equal(new.boundary.points(), cloud.boundary.points())
+    conv = []
+    wtp.repel(cloud, s, max_iters=30, tol=1e-12, stall_after=0, convergence=conv, ctx=ctx)
+    assert len(conv) == 30                                               # test/repel.jl:292-298
+    conv = []
+    c_t = wtp.repel(cloud, s, max_iters=200, tol=1e-12, cv_target=10.0, convergence=conv, ctx=ctx)
+    assert len(conv) == 1                                                # test/repel.jl:282-290
+    assert np.array_equal(c_t.volume.points(), cloud.volume.points())    # comes back untouched
+    conv = []
+    wtp.repel(cloud, s, max_iters=400, tol=1e-12, stall_after=5, convergence=conv, ctx=ctx)
+    assert 5 < len(conv) <= 400
+    with pytest.raises(wtp.WtpArgumentError):
+        wtp.repel(cloud, s, rebuild_every=0, ctx=ctx)                    # test/repel.jl:466
+
+
+def test_repel_matches_oracle_loop(ctx, O, wtp):
+    cloud = _cloud(wtp, dtype=np.float64)
+    s = 0.06
+    conv, trace = [], []
+    new = wtp.repel(cloud, s, max_iters=8, tol=0.0, stall_after=0, convergence=conv, trace=trace, ctx=ctx)
+    nb = len(cloud.boundary)
+    ref = O.relax_loop(wtp.points(cloud), nb, s, 2, 0.2, 1.0, 3.0, 21, s / 2000, s / 20, max_iters=8, tol=0.0,
+                       stall_after=0)
+    assert np.allclose(conv, ref["conv"], rtol=1e-12)
+    assert np.array_equal(new.volume.points(), ref["p"])                 # fp64 exact path: bit for bit
+    assert len(trace) == 8 and all(t["idx_a"] < t["idx_b"] for t in trace)
+
+
+def test_repel_variable_spacing_and_kick(ctx, wtp):
+    cloud = _cloud(wtp, dtype=np.float32)
+    sp = wtp.BoundaryLayerSpacing(cloud.boundary.points(), at_wall=0.04, bulk=0.08, layer_thickness=0.3)
+    conv = []
+    new = wtp.repel(cloud, sp, max_iters=5, stall_after=0, kick_after=2, convergence=conv, ctx=ctx)
+    assert len(conv) == 5 and np.isfinite(new.volume.points()).all()
+    sp2 = wtp.LogLike(cloud.boundary.points(), 0.08, 1.3)
+    assert wtp.repel(cloud, sp2, max_iters=2, stall_after=0, ctx=ctx).volume.points().shape == (len(cloud.volume), 3)
