@@ -71,6 +71,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal switches (not used by the driver): several ranks on ONE GPU over gloo, payloads
+    # staged through host memory — exercises the N>1 code path on a 1-GPU box
+    rehearsal = os.environ.get("WTP_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
@@ -78,7 +83,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     n_local = args.points
     n_total = n_local * world
@@ -105,7 +113,8 @@ def main():
 
         own_xyz, own_gid, cuts = sharded.uniform_shard(gen, rank, world, n_total, wtp_amd.synth.SEED, "cuda")
         drv = sharded.ShardedRelax(sharded.GpuEngine(ctx, s, force, k, s / 2000, s / 20), dist, own_xyz, own_gid, cuts,
-                                   sharded.ghost_width(n_total, k, ctx_rho()))
+                                   sharded.ghost_width(n_total, k, ctx_rho()),
+                                   comm_device="cpu" if rehearsal else None)
 
         def run(iters):
             drv.run(iters)
@@ -122,7 +131,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     tm = ctx.timers()

@@ -35,6 +35,11 @@ namespace wtp {
 constexpr int NB = 64;          // per-lane candidate ring / sorting-network width
 constexpr int kFastKMax = 32;   // k >= this goes to the wave kernel
 constexpr int kOwnRows = BY * BZ;
+#ifndef WTP_SCAN_U
+#define WTP_SCAN_U 8
+#endif
+constexpr int SCAN_U = WTP_SCAN_U;            // candidates per scan step (LDS reads issued together)
+constexpr int kPadBytes = SCAN_U * 16;         // reads past a run end stay inside this padding
 
 struct BrickSmem {
     int hstart[HCELLS + 1];   // LDS slot of the first point of each halo cell
@@ -126,8 +131,8 @@ template <int MODE, int KT>
 __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<float> a, int hcap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* pts = reinterpret_cast<float4*>(smem_raw);
-    uint16_t* ring_all = reinterpret_cast<uint16_t*>(smem_raw + (size_t)hcap * sizeof(float4) + 64);
-    BrickSmem* sm = reinterpret_cast<BrickSmem*>(smem_raw + (size_t)hcap * sizeof(float4) + 64 +
+    uint16_t* ring_all = reinterpret_cast<uint16_t*>(smem_raw + (size_t)hcap * sizeof(float4) + kPadBytes);
+    BrickSmem* sm = reinterpret_cast<BrickSmem*>(smem_raw + (size_t)hcap * sizeof(float4) + kPadBytes +
                                                  (size_t)(NB + 1) * kBrickThreads * sizeof(uint16_t));
     const int tid = threadIdx.x;
     uint16_t* ring = ring_all + tid; // entry j at ring[j * kBrickThreads]; row NB is a dump row
@@ -263,9 +268,9 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
 
             // ---- scan / select loop: one instance of the network serves prunes and the final cut
             // LDS byte addresses: points at [0, hcap*16), this lane's ring row j at ring_b + j*512
-            const uint32_t ring_b = (uint32_t)hcap * 16u + 64u + (uint32_t)tid * 2u;
+            const uint32_t ring_b = (uint32_t)hcap * 16u + (uint32_t)kPadBytes + (uint32_t)tid * 2u;
             const uint32_t dump_b = ring_b + (uint32_t)NB * (kBrickThreads * 2u);
-            const uint32_t full_b = ring_b + (uint32_t)(NB - 4) * (kBrickThreads * 2u);
+            const uint32_t full_b = ring_b + (uint32_t)(NB - SCAN_U) * (kBrickThreads * 2u);
             uint32_t ra = ring_b; // next free ring entry
             int row = 0;
             uint32_t pa, ea;      // current candidate run [pa, ea) as byte offsets into pts
@@ -283,22 +288,25 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
                             pressure = true;
                             break;
                         }
-                        // 4 candidates per step: reads first (one wait), then branch-free appends.
+                        // SCAN_U candidates per step: reads first (one wait), then branch-free appends.
                         // Reads past the run end stay inside the padded point area and are masked.
-                        float4 c[4];
+                        float4 c[SCAN_U];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
+                        for (int u = 0; u < SCAN_U; ++u) {
                             c[u] = *reinterpret_cast<const float4*>(smem_raw + pa + 16u * u);
                         }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
+                        for (int u = 0; u < SCAN_U; ++u) {
                             const float d = dist2<float>(qp.x, qp.y, qp.z, c[u].x, c[u].y, c[u].z);
-                            // the id compare also keeps .w live: one ds_read_b128 per point, not b96
-                            const bool take = (pa + 16u * u < ea) && (d <= tau) && (w_to_id(c[u].w) != skip_id);
+                            // run-end masking folded into the threshold (a VALU select) instead of
+                            // and-ing lane masks on the scalar unit: no VALU->SALU->VALU round trip
+                            const float tl = (pa + 16u * u < ea) ? tau : -1.f;
+                            bool take = d <= tl;
+                            if (MODE == 0) take = take && (w_to_id(c[u].w) != skip_id);
                             *reinterpret_cast<uint16_t*>(smem_raw + (take ? ra : dump_b)) = (uint16_t)(pa + 16u * u);
                             ra += take ? (kBrickThreads * 2u) : 0u;
                         }
-                        pa += 64u;
+                        pa += 16u * SCAN_U;
                     }
                     if (pressure) break;
                     ++row;
@@ -322,7 +330,7 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
                     tau = t < tau ? t : tau;
                 }
                 ring_compact(pts, ring, cnt, tau, qp.x, qp.y, qp.z);
-                if (cnt > NB - 4) { // ring still full (mass tie): give up, the wave kernel takes it
+                if (cnt > NB - SCAN_U) { // ring still full (mass tie): give up, the wave kernel takes it
                     giveup = true;
                     cnt = 0;
                     tau = -1.f;
@@ -427,7 +435,7 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
 }
 
 static size_t brick_smem_bytes(int hcap) {
-    return (size_t)hcap * sizeof(float4) + 64 + (size_t)(NB + 1) * kBrickThreads * sizeof(uint16_t) + sizeof(BrickSmem);
+    return (size_t)hcap * sizeof(float4) + kPadBytes + (size_t)(NB + 1) * kBrickThreads * sizeof(uint16_t) + sizeof(BrickSmem);
 }
 
 // LDS budget: 160 KiB per CU; hcap sized so two workgroups fit.
