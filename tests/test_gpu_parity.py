@@ -55,7 +55,8 @@ def test_knn_errors(ctx, wtp):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("dim,n,r", [(2, 500, 0.1), (3, 4000, 0.08), (3, 30000, 0.03), (3, 300, 5.0), (3, 300, 0.0)])
+@pytest.mark.parametrize("dim,n,r", [(2, 500, 0.1), (3, 4000, 0.08), (3, 30000, 0.03), (3, 300, 5.0), (3, 300, 0.0),
+                                     (3, 1500, 5.0)])  # last: rows of 1499 > the wave kernel's LDS list
 def test_radius_matches_oracle(ctx, O, wtp, dtype, dim, n, r):
     x = _cloud(wtp, n, dim, dtype)
     off, idx = ctx.radius(x, r)

@@ -303,6 +303,8 @@ template <typename T> static int radius_fill_t(wtp_ctx* ctx, const int64_t* d_of
     a.query = a.snap;
     a.cell_start = (const int32_t*)ctx->cell_start.p;
     a.n = (int32_t)ctx->rad_n;
+    a.fb2_list = (int32_t*)ctx->fb2_list.p;
+    a.fb2_count = (int32_t*)ctx->fb2_count.p;
     int sp = span_begin(ctx, 1);
     int rc = launch_radius_fill<T>(ctx, a, (T)ctx->rad_r, d_off, d_idx);
     span_end(ctx, sp);
@@ -352,6 +354,8 @@ WTP_API int wtp_radius_fill(wtp_ctx* ctx, const int64_t* offsets, int32_t* idx_o
     if ((rc = ensure(ctx, ctx->idx_out, sizeof(int32_t) * (size_t)(nnz + 1)))) return rc;
     if ((rc = ensure(ctx, ctx->scratch, ts * (size_t)(nnz + 1)))) return rc;
     if ((rc = ensure(ctx, ctx->dist_out, sizeof(int64_t) * (size_t)(n + 1)))) return rc; // offsets staging
+    if ((rc = ensure(ctx, ctx->fb2_list, sizeof(int32_t) * (size_t)n))) return rc;
+    if ((rc = ensure(ctx, ctx->fb2_count, 64))) return rc;
     WTP_HIP(ctx, hipMemcpyAsync(ctx->dist_out.p, offsets, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyHostToDevice,
                                 ctx->stream));
     rc = ctx->rad_dtype == WTP_F32 ? radius_fill_t<float>(ctx, (const int64_t*)ctx->dist_out.p, (int32_t*)ctx->idx_out.p)

@@ -112,10 +112,14 @@ __global__ __launch_bounds__(kThreads) void generic_kernel(SearchArgs<T> a, cons
 template <typename T, bool FILL>
 __global__ __launch_bounds__(kThreads) void radius_kernel(SearchArgs<T> a, T r, int32_t* __restrict__ counts,
                                                           const int64_t* __restrict__ offsets,
-                                                          int32_t* __restrict__ idx_out, T* __restrict__ d2_tmp) {
+                                                          int32_t* __restrict__ idx_out, T* __restrict__ d2_tmp,
+                                                          const int32_t* __restrict__ list,
+                                                          const int32_t* __restrict__ list_count) {
     const Grid<T> g = *a.grid;
     const T r2 = r * r; // compared as d2 <= r*r, inclusive (inrange, src/topology.jl:93-94)
-    for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < a.n; slot += gridDim.x * blockDim.x) {
+    const int nq = list ? *list_count : a.n;
+    for (int qi = blockIdx.x * blockDim.x + threadIdx.x; qi < nq; qi += gridDim.x * blockDim.x) {
+        const int slot = list ? list[qi] : qi;
         const Pt<T> q = a.snap[slot];
         const int32_t id = w_to_id(q.w);
         const int cx = cell_coord(g, q.x, 0), cy = cell_coord(g, q.y, 1), cz = cell_coord(g, q.z, 2);
@@ -201,16 +205,32 @@ template <typename T> int launch_generic_sweep(wtp_ctx* ctx, SearchArgs<T>& a, b
 
 template <typename T>
 int launch_radius_count(wtp_ctx* ctx, SearchArgs<T>& a, T r, int32_t* d_counts) {
-    hipLaunchKernelGGL((radius_kernel<T, false>), dim3(blocks_for(a.n, 65536)), dim3(kThreads), 0, ctx->stream,
-                       a, r, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (T*)nullptr);
-    WTP_HIP(ctx, hipGetLastError());
-    return WTP_OK;
+    if (ctx->force_generic == 2) {
+        hipLaunchKernelGGL((radius_kernel<T, false>), dim3(blocks_for(a.n, 65536)), dim3(kThreads), 0, ctx->stream,
+                           a, r, d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, (T*)nullptr,
+                           (const int32_t*)nullptr, (const int32_t*)nullptr);
+        WTP_HIP(ctx, hipGetLastError());
+        return WTP_OK;
+    }
+    return launch_wave_radius_count<T>(ctx, a, r, d_counts);
 }
 
+// Rows are ranked by the wave kernel; rows longer than its LDS list (fb2 list) are insertion-
+// sorted in place by the serial kernel, which needs a d2 scratch row (ctx->scratch).
 template <typename T>
 int launch_radius_fill(wtp_ctx* ctx, SearchArgs<T>& a, T r, const int64_t* d_offsets, int32_t* d_idx) {
-    hipLaunchKernelGGL((radius_kernel<T, true>), dim3(blocks_for(a.n, 65536)), dim3(kThreads), 0, ctx->stream,
-                       a, r, (int32_t*)nullptr, d_offsets, d_idx, (T*)ctx->scratch.p);
+    if (ctx->force_generic == 2) {
+        hipLaunchKernelGGL((radius_kernel<T, true>), dim3(blocks_for(a.n, 65536)), dim3(kThreads), 0, ctx->stream,
+                           a, r, (int32_t*)nullptr, d_offsets, d_idx, (T*)ctx->scratch.p, (const int32_t*)nullptr,
+                           (const int32_t*)nullptr);
+        WTP_HIP(ctx, hipGetLastError());
+        return WTP_OK;
+    }
+    WTP_HIP(ctx, hipMemsetAsync(a.fb2_count, 0, sizeof(int32_t), ctx->stream));
+    int rc = launch_wave_radius_fill<T>(ctx, a, r, d_offsets, d_idx);
+    if (rc) return rc;
+    hipLaunchKernelGGL((radius_kernel<T, true>), dim3(256), dim3(kThreads), 0, ctx->stream, a, r, (int32_t*)nullptr,
+                       d_offsets, d_idx, (T*)ctx->scratch.p, (const int32_t*)a.fb2_list, (const int32_t*)a.fb2_count);
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;
 }

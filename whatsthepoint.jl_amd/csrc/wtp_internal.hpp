@@ -202,6 +202,9 @@ template <typename T> int launch_sweep(wtp_ctx* ctx, SearchArgs<T>& a, bool fres
 // exact paths: wave-per-query (list = fb_list or all points), then the serial kernel on fb2_list
 template <typename T> int launch_wave_topology(wtp_ctx* ctx, SearchArgs<T>& a, bool all);
 template <typename T> int launch_wave_sweep(wtp_ctx* ctx, SearchArgs<T>& a, bool all);
+template <typename T> int launch_wave_radius_count(wtp_ctx* ctx, SearchArgs<T>& a, T r, int32_t* d_counts);
+template <typename T>
+int launch_wave_radius_fill(wtp_ctx* ctx, SearchArgs<T>& a, T r, const int64_t* d_offsets, int32_t* d_idx);
 template <typename T> int launch_generic_topology(wtp_ctx* ctx, SearchArgs<T>& a, bool all);
 template <typename T> int launch_generic_sweep(wtp_ctx* ctx, SearchArgs<T>& a, bool all);
 inline int total_partials() { return brick_partials() + kWavePartials + kGenericPartials; }

@@ -246,7 +246,109 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
     }
 }
 
+// ---- RadiusTopology, wave per point (src/topology.jl:91-97) --------------------------------------
+// The hash was built with cell edge >= r, so the 3^dim cell block is complete.  COUNT: ballot +
+// popcount of d2 <= r*r (self removed by index).  FILL: hits go to the per-wave LDS list, each
+// lane ranks its entry by the canonical (d2, index) order with a broadcast compare loop and
+// writes it to its final place in the CSR row.  Rows longer than the LDS list are handed to the
+// serial kernel (wtp_generic.hip) through the fb2 list.
+template <typename T, bool FILL>
+__global__ __launch_bounds__(kThreads) void wave_radius_kernel(SearchArgs<T> a, T r, int32_t* __restrict__ counts,
+                                                               const int64_t* __restrict__ offsets,
+                                                               int32_t* __restrict__ idx_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    WaveSmem<T>* sm = reinterpret_cast<WaveSmem<T>*>(smem_raw) + wave;
+    const Grid<T> g = *a.grid;
+    const T r2 = r * r; // inclusive, compared as d2 <= r*r
+    const int wave_global = blockIdx.x * kWaves + wave;
+    const int wave_stride = gridDim.x * kWaves;
+    for (int slot = wave_global; slot < a.n; slot += wave_stride) {
+        const Pt<T> q = a.snap[slot];
+        const int32_t id = w_to_id(q.w);
+        const int cx = cell_coord(g, q.x, 0), cy = cell_coord(g, q.y, 1), cz = cell_coord(g, q.z, 2);
+        const int z0 = cz - 1 < 0 ? 0 : cz - 1, z1 = cz + 1 > g.n[2] - 1 ? g.n[2] - 1 : cz + 1;
+        const int y0 = cy - 1 < 0 ? 0 : cy - 1, y1 = cy + 1 > g.n[1] - 1 ? g.n[1] - 1 : cy + 1;
+        const int x0 = cx - 1 < 0 ? 0 : cx - 1, x1 = cx + 1 > g.n[0] - 1 ? g.n[0] - 1 : cx + 1;
+        int m = 0;
+        for (int z = z0; z <= z1; ++z)
+            for (int y = y0; y <= y1; ++y) {
+                const int row = (z * g.n[1] + y) * g.n[0];
+                const int ps = a.cell_start[row + x0], pe = a.cell_start[row + x1 + 1];
+                for (int p0 = ps; p0 < pe; p0 += 64) {
+                    const int p = p0 + lane;
+                    bool take = false;
+                    T d = 0;
+                    int32_t cid = 0;
+                    if (p < pe) {
+                        const Pt<T> c = a.snap[p];
+                        cid = w_to_id(c.w);
+                        d = dist2<T>(q.x, q.y, q.z, c.x, c.y, c.z);
+                        take = (d <= r2) && (cid != id); // filter(!=(i), n), src/topology.jl:96
+                    }
+                    const unsigned long long mask = __ballot(take);
+                    if (FILL) {
+                        const int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
+                        if (take && pos < kCap) {
+                            sm->d2[pos] = d;
+                            sm->id[pos] = cid;
+                        }
+                    }
+                    m += __popcll(mask);
+                }
+            }
+        if (!FILL) {
+            if (lane == 0) counts[id] = m;
+            continue;
+        }
+        if (m > kCap) { // row longer than the LDS list: serial kernel
+            if (lane == 0) {
+                const int pos = atomicAdd(a.fb2_count, 1);
+                a.fb2_list[pos] = slot;
+            }
+            continue;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int64_t base = offsets[id];
+        const int64_t cap = offsets[id + 1] - base;
+        for (int i = lane; i < m; i += 64) {
+            const T md = sm->d2[i];
+            const int32_t mi = sm->id[i];
+            int rank = 0;
+            for (int j = 0; j < m; ++j) rank += lex_lt(sm->d2[j], sm->id[j], md, mi) ? 1 : 0;
+            if (rank < cap) idx_out[base + rank] = mi;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 template <typename T> static size_t wave_smem() { return sizeof(WaveSmem<T>) * kWaves + sizeof(Acc) * kWaves; }
+
+template <typename T> int launch_wave_radius_count(wtp_ctx* ctx, SearchArgs<T>& a, T r, int32_t* d_counts) {
+    int64_t want = ((int64_t)a.n + kWaves - 1) / kWaves;
+    int nb = (int)(want > 16384 ? 16384 : (want < 1 ? 1 : want));
+    hipLaunchKernelGGL((wave_radius_kernel<T, false>), dim3(nb), dim3(kThreads), 0, ctx->stream, a, r,
+                       d_counts, (const int64_t*)nullptr, (int32_t*)nullptr);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
+template <typename T>
+int launch_wave_radius_fill(wtp_ctx* ctx, SearchArgs<T>& a, T r, const int64_t* d_offsets, int32_t* d_idx) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)wave_radius_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)wave_smem<T>());
+        attr_set = true;
+    }
+    int64_t want = ((int64_t)a.n + kWaves - 1) / kWaves;
+    int nb = (int)(want > 16384 ? 16384 : (want < 1 ? 1 : want));
+    hipLaunchKernelGGL((wave_radius_kernel<T, true>), dim3(nb), dim3(kThreads), wave_smem<T>(), ctx->stream, a, r,
+                       (int32_t*)nullptr, d_offsets, d_idx);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
 
 template <typename T, int MODE> static int launch_wave(wtp_ctx* ctx, SearchArgs<T>& a, bool all, int part_base) {
     static bool attr_set = false;
@@ -271,8 +373,10 @@ template <typename T> int launch_wave_sweep(wtp_ctx* ctx, SearchArgs<T>& a, bool
     return launch_wave<T, 1>(ctx, a, all, brick_partials());
 }
 
-#define INST(T)                                                               \
-    template int launch_wave_topology<T>(wtp_ctx*, SearchArgs<T>&, bool);     \
+#define INST(T)                                                                                  \
+    template int launch_wave_topology<T>(wtp_ctx*, SearchArgs<T>&, bool);                        \
+    template int launch_wave_radius_count<T>(wtp_ctx*, SearchArgs<T>&, T, int32_t*);             \
+    template int launch_wave_radius_fill<T>(wtp_ctx*, SearchArgs<T>&, T, const int64_t*, int32_t*); \
     template int launch_wave_sweep<T>(wtp_ctx*, SearchArgs<T>&, bool);
 INST(float)
 INST(double)
