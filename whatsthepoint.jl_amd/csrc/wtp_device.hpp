@@ -33,6 +33,9 @@ __device__ inline T dist2(T ax, T ay, T az, T bx, T by, T bz) {
     return s + dz * dz;
 }
 
+// (Measured on gfx950: v_pk_add_f32 / v_pk_mul_f32 issue at half the rate of the scalar forms, so
+// packing the (x,y) pair buys nothing — profiles/r01_d_ablation.txt.)
+
 template <typename T>
 __device__ inline bool lex_lt(T da, int32_t ia, T db, int32_t ib) {
     return (da < db) || (da == db && ia < ib);

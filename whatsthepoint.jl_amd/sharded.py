@@ -71,17 +71,20 @@ class ShardedRelax:
         self.history = []
 
     # ---- point-to-point exchange with the two slab neighbours ------------------------------------
-    def _exchange(self, to_lo: torch.Tensor, to_hi: torch.Tensor):
-        """Send `to_lo` to rank-1 and `to_hi` to rank+1; return (from_lo, from_hi).  Payload rows
-        are [x, y, z, gid_lo_bits, gid_hi_bits] as float32-compatible words packed in an int32 view."""
+    def _exchange(self, to_lo: torch.Tensor, split_lo: int, to_hi: torch.Tensor, split_hi: int):
+        """One round: send `to_lo` to rank-1 and `to_hi` to rank+1.  Each payload is
+        [migrants ; ghost layer] with `split_*` migrants first; rows are
+        [x, y, z, gid_lo_bits, gid_hi_bits] as int32 words.  Returns
+        (from_lo, n_migrants_from_lo, from_hi, n_migrants_from_hi)."""
         d, r, W = self.dist, self.rank, self.world
         lo, hi = r - 1, r + 1
         to_lo, to_hi = to_lo.to(self.cdev), to_hi.to(self.cdev)
-        cnt_send = torch.tensor([to_lo.shape[0], to_hi.shape[0]], dtype=torch.int64, device=self.cdev)
-        cnt_all = [torch.zeros(2, dtype=torch.int64, device=self.cdev) for _ in range(W)]
+        cnt_send = torch.tensor([split_lo, to_lo.shape[0], split_hi, to_hi.shape[0]], dtype=torch.int64, device=self.cdev)
+        cnt_all = [torch.zeros(4, dtype=torch.int64, device=self.cdev) for _ in range(W)]
         d.all_gather(cnt_all, cnt_send)
-        n_from_lo = int(cnt_all[lo][1].item()) if lo >= 0 else 0
-        n_from_hi = int(cnt_all[hi][0].item()) if hi < W else 0
+        cnt = torch.stack(cnt_all).cpu()
+        m_from_lo, n_from_lo = (int(cnt[lo, 2]), int(cnt[lo, 3])) if lo >= 0 else (0, 0)
+        m_from_hi, n_from_hi = (int(cnt[hi, 0]), int(cnt[hi, 1])) if hi < W else (0, 0)
         cols = to_lo.shape[1]
         from_lo = torch.empty((n_from_lo, cols), dtype=to_lo.dtype, device=self.cdev)
         from_hi = torch.empty((n_from_hi, cols), dtype=to_lo.dtype, device=self.cdev)
@@ -99,7 +102,7 @@ class ShardedRelax:
         if ops:
             for req in d.batch_isend_irecv(ops):
                 req.wait()
-        return from_lo.to(self.dev), from_hi.to(self.dev)
+        return from_lo.to(self.dev), m_from_lo, from_hi.to(self.dev), m_from_hi
 
     def _pack(self, mask):
         gid = self.gid[mask]
@@ -120,25 +123,29 @@ class ShardedRelax:
     # ---- one iteration ---------------------------------------------------------------------------------
     def step(self):
         lo, hi = self._bounds()
-        z = self.xyz[:, 2]
-        # 1. migration: points that crossed a cut move to the neighbour slab (|disp| <= s << slab)
-        go_lo, go_hi = z < lo, z >= hi
         if self.world > 1:
-            keep = ~(go_lo | go_hi)
-            from_lo, from_hi = self._exchange(self._pack(go_lo), self._pack(go_hi))
-            parts_x, parts_g = [self.xyz[keep]], [self.gid[keep]]
-            for b in (from_lo, from_hi):
-                if b.shape[0]:
-                    x, g = self._unpack(b, self.xyz.dtype)
-                    parts_x.append(x)
-                    parts_g.append(g)
-            self.xyz, self.gid = torch.cat(parts_x), torch.cat(parts_g)
             z = self.xyz[:, 2]
-        # 2. ghost layer: foreign points within w of my slab
-        if self.world > 1:
-            g_lo, g_hi = self._exchange(self._pack(z < lo + self.w), self._pack(z >= hi - self.w))
-            gx = [self._unpack(b, self.xyz.dtype)[0] for b in (g_lo, g_hi) if b.shape[0]]
-            ghosts = torch.cat(gx) if gx else self.xyz[:0]
+            # 1. who leaves (crossed a cut; |disp| <= s << slab) and who is ghost material
+            #    (stays mine, within w of a cut) — one exchange round carries both
+            go_lo, go_hi = z < lo, z >= hi
+            keep = ~(go_lo | go_hi)
+            gl_lo, gl_hi = keep & (z < lo + self.w), keep & (z >= hi - self.w)
+            mig_lo, mig_hi = self._pack(go_lo), self._pack(go_hi)
+            from_lo, m_lo, from_hi, m_hi = self._exchange(
+                torch.cat([mig_lo, self._pack(gl_lo)]), int(mig_lo.shape[0]),
+                torch.cat([mig_hi, self._pack(gl_hi)]), int(mig_hi.shape[0]))
+            # 2. ghosts = the neighbours' layers + my own emigrants (they now belong to a neighbour
+            #    but sit within reach of my slab; the neighbour's layer was cut before they arrived)
+            gx = [self.xyz[go_lo], self.xyz[go_hi]]
+            parts_x, parts_g = [self.xyz[keep]], [self.gid[keep]]
+            for buf, m in ((from_lo, m_lo), (from_hi, m_hi)):
+                if buf.shape[0]:
+                    x, g = self._unpack(buf, self.xyz.dtype)
+                    parts_x.append(x[:m])
+                    parts_g.append(g[:m])
+                    gx.append(x[m:])
+            self.xyz, self.gid = torch.cat(parts_x), torch.cat(parts_g)
+            ghosts = torch.cat(gx)
         else:
             ghosts = self.xyz[:0]
         n_ghost = int(ghosts.shape[0])
@@ -205,12 +212,21 @@ def uniform_shard(ctx_gen, rank: int, world: int, n_total: int, seed: int, devic
         xs.append(x[m])
         gs.append(torch.nonzero(m).reshape(-1).to(torch.int64) + first)
     cuts = [(r + 1) / world for r in range(world - 1)]
-    return torch.cat(xs).contiguous(), torch.cat(gs).contiguous(), cuts
+    xyz, gid = torch.cat(xs).contiguous(), torch.cat(gs).contiguous()
+    # keep the owned array in cell order from the start: libwtp returns points in the order they
+    # were handed over, so every later rebuild reads a nearly sorted array (coalesced scatter)
+    cell = max((float(n_total) ** (-1.0 / 3.0)) * 2.0, 1e-6)
+    key = torch.floor(xyz / cell).to(torch.int64)
+    order = torch.argsort((key[:, 2] * 4096 + key[:, 1]) * 4096 + key[:, 0], stable=True)
+    return xyz[order].contiguous(), gid[order].contiguous(), cuts
 
 
-def ghost_width(n_total: int, k: int, rho: float = 8.0, ghost_cells: float = 3.0, dim: int = 3) -> float:
+def ghost_width(n_total: int, k: int, rho: float = 8.0, ghost_cells: float = 2.0, dim: int = 3) -> float:
     """ghost_cells x the hash cell edge libwtp will choose for this density (csrc/wtp_hash.hip
-    build_hash: c = (rho_k / density)^(1/dim), rho_k = 0.381 k rho/8).  3 cells cover the fast
-    path's certificate radius (1.08 c) and the wave kernel's first ring (2.5 c)."""
+    build_hash: c = (rho_k / density)^(1/dim), rho_k = 0.381 k rho/8; c ~ 1.17 r_k).
+    Correctness needs every owned query's k nearest points to be present locally, i.e.
+    w >= max r_k.  2 cells = 2.3x the mean r_k: a ball of that radius holds ~270 points at the
+    benchmark density, so a k=21 query cannot reach past it.  (A local certificate clamped to the
+    ghost extent, for strongly graded clouds, is future work: DESIGN.md §7.)"""
     rho_k = (0.381 if dim == 3 else 0.436) * k * (rho / 8.0)
     return ghost_cells * (max(rho_k, 1.0) / n_total) ** (1.0 / dim)
