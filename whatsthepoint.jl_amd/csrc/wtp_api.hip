@@ -219,7 +219,7 @@ WTP_API int wtp_destroy(wtp_ctx* ctx) {
                       &ctx->cell_cnt, &ctx->cell_start, &ctx->scan_tmp, &ctx->grid, &ctx->bbox_part,
                       &ctx->idx_out, &ctx->dist_out, &ctx->counts_out, &ctx->forces, &ctx->nn_dist,
                       &ctx->nn_id, &ctx->spacing_pp, &ctx->partials, &ctx->stats, &ctx->fb_list,
-                      &ctx->fb_count, &ctx->fb2_list, &ctx->fb2_count, &ctx->scratch};
+                      &ctx->fb_count, &ctx->fb2_list, &ctx->fb2_count, &ctx->scratch, &ctx->diag};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     if (ctx->host_pinned) hipHostFree(ctx->host_pinned);
@@ -504,6 +504,8 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
     a.fb_count = (int32_t*)ctx->fb_count.p;
     a.fb2_list = (int32_t*)ctx->fb2_list.p;
     a.fb2_count = (int32_t*)ctx->fb2_count.p;
+    if ((rc = ensure(ctx, ctx->diag, 128))) return rc;
+    a.diag = (unsigned long long*)ctx->diag.p;
     if ((rc = launch_sweep<T>(ctx, a, fresh))) return rc;
     int sp = span_begin(ctx, 2);
     rc = launch_reduce_partials(ctx, a.partials, a.n_partials, a.fb_count, d_slot);
@@ -710,6 +712,18 @@ WTP_API int wtp_timers_reset(wtp_ctx* ctx) {
     ctx->t_hash = ctx->t_sweep = ctx->t_other = 0;
     ctx->n_sweep_launches = 0;
     return WTP_OK;
+}
+
+// Diagnostic builds (-DWTP_DIAG): per-phase wave-cycle sums of the brick kernel, accumulated
+// over all launches since the last call; reading resets them.  Release builds leave zeros.
+WTP_API int wtp_debug_diag(wtp_ctx* ctx, unsigned long long out[8]) {
+    if (!ctx || !out) return WTP_ERR_ARG;
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, ctx->diag, 128))) return rc;
+    WTP_HIP(ctx, hipMemcpyAsync(out, ctx->diag.p, 64, hipMemcpyDeviceToHost, ctx->stream));
+    WTP_HIP(ctx, hipMemsetAsync(ctx->diag.p, 0, 128, ctx->stream));
+    return sync(ctx);
 }
 
 // ---- device-side helpers for bench.py / the sharded driver (not part of the drop-in surface) -----

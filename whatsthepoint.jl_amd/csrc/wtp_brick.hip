@@ -29,6 +29,15 @@
 
 namespace wtp {
 
+#ifndef WTP_DIAG
+#define WTP_DIAG 0 // diagnostic build: s_memtime stamps per phase (never quote its run time)
+#endif
+#define DIAG_STAMP(i)                                              \
+    if (WTP_DIAG) {                                                \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        dt[i] += t_ - t_last;                                      \
+        t_last = t_;                                               \
+    }
 #ifndef WTP_ABL
 #define WTP_ABL 0 // timing-only ablation builds (results wrong): 1 no force pass, 2 no select, 4 no scan
 #endif
@@ -38,6 +47,7 @@ constexpr int kOwnRows = BY * BZ;
 #ifndef WTP_SCAN_U
 #define WTP_SCAN_U 8
 #endif
+static_assert(WTP_SCAN_U == 8, "lds_read_group is written for 8 points per step");
 constexpr int SCAN_U = WTP_SCAN_U;            // candidates per scan step (LDS reads issued together)
 constexpr int kPadBytes = SCAN_U * 16;         // reads past a run end stay inside this padding
 
@@ -60,6 +70,27 @@ struct BrickSmem {
 // ring entries are byte offsets into the staged point area (< 64 KiB)
 __device__ inline float4 lds_pt(const float4* pts, uint32_t byte_off) {
     return *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(pts) + byte_off);
+}
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// SCAN_U consecutive staged points in one go: explicit ds_read_b128 (the compiler would shrink
+// the loads to b96 when .w is unused, which costs twice the LDS cycles per instruction) and a
+// single wait.  The wait is inside the statement, so the outputs are valid when it returns.
+__device__ inline void lds_read_group(f4 (&c)[8], uint32_t addr) {
+    asm volatile(
+        "ds_read_b128 %0, %8\n\t"
+        "ds_read_b128 %1, %8 offset:16\n\t"
+        "ds_read_b128 %2, %8 offset:32\n\t"
+        "ds_read_b128 %3, %8 offset:48\n\t"
+        "ds_read_b128 %4, %8 offset:64\n\t"
+        "ds_read_b128 %5, %8 offset:80\n\t"
+        "ds_read_b128 %6, %8 offset:96\n\t"
+        "ds_read_b128 %7, %8 offset:112\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7])
+        : "v"(addr)
+        : "memory");
 }
 
 __device__ inline uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
@@ -115,16 +146,30 @@ __device__ inline void ring_compact(const float4* __restrict__ pts, uint16_t* __
     cnt = keep;
 }
 
-// Fast-math force law for the brick path (1-ulp rcp/rsq; the wave kernel keeps the IEEE forms):
-// returns f(u) with u2 = d2/s^2.
-__device__ inline float force_fast(int kind, float beta, float u0sq, float gamma, float u2) {
-    const float d = u2 + beta;
-    if (kind == WTP_FORCE_STRONG_SPACING) return (1.f - u2) * __builtin_amdgcn_exp2f(-gamma * __builtin_amdgcn_logf(d));
-    const float inv = __builtin_amdgcn_rcpf(d * d);
-    if (kind == WTP_FORCE_INVERSE_DISTANCE) return inv;
-    if (kind == WTP_FORCE_SPACING_EQUILIBRIUM) return (1.f - u2) * inv;
-    const float f = (u0sq - u2) * inv;
-    return f > 0.f ? f : 0.f;
+// Fast-math force law for the brick path (1-ulp rcp; the wave kernel keeps the IEEE forms).
+// Laws 0..2 are one branch-free expression  max((A - B*u2) / (u2+beta)^2, lo)  with
+// (A,B,lo) = (1,0,-inf) inverse distance, (1,1,-inf) equilibrium, (u0^2,1,0) clipped; law 3 swaps the
+// denominator for (u2+beta)^gamma.  u2 = d2/s^2.
+struct ForceCoef {
+    float A, B, lo, beta, gamma;
+    int strong;
+};
+__device__ inline ForceCoef force_coef(int kind, float beta, float u0, float gamma) {
+    ForceCoef c;
+    c.A = kind == WTP_FORCE_CLIPPED_SPACING ? u0 * u0 : 1.f;
+    c.B = kind == WTP_FORCE_INVERSE_DISTANCE ? 0.f : 1.f;
+    c.lo = kind == WTP_FORCE_CLIPPED_SPACING ? 0.f : -Lim<float>::inf();
+    c.beta = beta;
+    c.gamma = gamma;
+    c.strong = kind == WTP_FORCE_STRONG_SPACING;
+    return c;
+}
+__device__ inline float force_fast(const ForceCoef& c, float u2) {
+    const float d = u2 + c.beta;
+    float inv = __builtin_amdgcn_rcpf(d * d);
+    if (c.strong) inv = __builtin_amdgcn_exp2f(-c.gamma * __builtin_amdgcn_logf(d)); // wave-uniform
+    const float f = (c.A - c.B * u2) * inv;
+    return f > c.lo ? f : c.lo;
 }
 
 template <int MODE, int KT>
@@ -142,6 +187,8 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
     const bool skip_self = (MODE == 0) && !a.include_self;
     const float cap2 = (a.gamma_cap * g.c) * (a.gamma_cap * g.c);
     Acc acc = acc_empty();
+    unsigned long long dt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_last = WTP_DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
     // masked-off ring reads use row 0: make every slot ever read from it a valid LDS point index
 #pragma unroll 1
     for (int j = 0; j <= NB; ++j) ring[j * kBrickThreads] = 0;
@@ -230,6 +277,7 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
         __syncthreads();
 
         // ---- 4. queries -----------------------------------------------------------------------
+        DIAG_STAMP(0) // brick setup + halo staging
         const int Q = sm->own_pref[kOwnRows];
         for (int qb = 0; qb < Q; qb += kBrickThreads) {
             const int q = qb + tid;
@@ -272,6 +320,8 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
             const uint32_t dump_b = ring_b + (uint32_t)NB * (kBrickThreads * 2u);
             const uint32_t full_b = ring_b + (uint32_t)(NB - SCAN_U) * (kBrickThreads * 2u);
             uint32_t ra = ring_b; // next free ring entry
+            const uint32_t lds_base = (uint32_t)(uintptr_t)smem_raw; // LDS byte address of the point area
+            DIAG_STAMP(1) // query setup
             int row = 0;
             uint32_t pa, ea;      // current candidate run [pa, ea) as byte offsets into pts
             {
@@ -283,18 +333,17 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
             for (;;) {
                 bool pressure = false;
                 while (row < 9) {
+                    // SCAN_U candidates per step: all reads issued together (one wait), then
+                    // branch-free appends.  Reads past the run end stay inside the padded point
+                    // area and are masked.  (A ping-pong prefetch of the next step was measured
+                    // slower: the LDS pipe, not its latency, is the co-bottleneck.)
                     while (!(WTP_ABL & 4) && __any(pa < ea)) {
                         if (__any(ra > full_b)) {
                             pressure = true;
                             break;
                         }
-                        // SCAN_U candidates per step: reads first (one wait), then branch-free appends.
-                        // Reads past the run end stay inside the padded point area and are masked.
-                        float4 c[SCAN_U];
-#pragma unroll
-                        for (int u = 0; u < SCAN_U; ++u) {
-                            c[u] = *reinterpret_cast<const float4*>(smem_raw + pa + 16u * u);
-                        }
+                        f4 c[SCAN_U];
+                        lds_read_group(c, lds_base + pa);
 #pragma unroll
                         for (int u = 0; u < SCAN_U; ++u) {
                             const float d = dist2<float>(qp.x, qp.y, qp.z, c[u].x, c[u].y, c[u].z);
@@ -322,7 +371,9 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
                     kth = f2u(tau);
                     next = kth + 1;
                 } else {
+                    DIAG_STAMP(2) // scan
                     ring_select<KT>(pts, ring, cnt, qp.x, qp.y, qp.z, K, kth, next);
+                    DIAG_STAMP(3) // select
                 }
                 if (!pressure) break;
                 if (cnt >= K) {
@@ -336,6 +387,7 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
                     tau = -1.f;
                 }
                 ra = ring_b + (uint32_t)cnt * (kBrickThreads * 2u);
+                DIAG_STAMP(4) // prune compaction
             }
 
             bool fallback = !WTP_ABL && ((cnt < K) || giveup || (kth == next)); // tie exactly at the cut -> exact path
@@ -370,6 +422,8 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
                     // ClippedSpacingForce vanishes for u >= u0: neighbours beyond u0*s add nothing
                     const float lim = (a.force_kind == WTP_FORCE_CLIPPED_SPACING && u0sq * (s * s) < cut)
                                           ? u0sq * (s * s) : cut;
+                    const ForceCoef fc = force_coef(a.force_kind, a.beta, a.u0, a.gamma);
+                    bool coincident = false;
                     float Fx = 0.f, Fy = 0.f, Fz = 0.f;
                     int32_t nid = 0x7FFFFFFF;
                     float nd2 = Lim<float>::inf();
@@ -393,21 +447,18 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
                             nd2 = nearer ? d : nd2;
                             nid = nearer ? cid : nid;
                             const bool act = in && (d <= lim);
-                            const float f = force_fast(a.force_kind, a.beta, u0sq, a.gamma, d * inv_s2);
+                            const float f = force_fast(fc, d * inv_s2);
                             const float coef = (act && d > 0.f) ? f * __builtin_amdgcn_rsqf(d) : 0.f;
                             Fx += coef * dx;
                             Fy += coef * dy;
                             Fz += coef * dz;
-                            if (__any(act && !(d > 0.f))) { // coincident points: rare
-                                if (act && !(d > 0.f)) {
-                                    float dir[3];
-                                    fallback_dir<float>(qid, cid, g.dim, dir);
-                                    Fx += f * dir[0];
-                                    Fy += f * dir[1];
-                                    Fz += f * dir[2];
-                                }
-                            }
+                            coincident = coincident || (act && !(d > 0.f));
                         }
+                    }
+                    if (coincident) { // r == 0 needs the substitute direction: exact path (rare)
+                        const int pos = atomicAdd(a.fb_count, 1);
+                        a.fb_list[pos] = gslot;
+                        continue;
                     }
                     float4 o;
                     const float f = step_point<float>(a, s, qp.x, qp.y, qp.z, Fx, Fy, Fz, o.x, o.y, o.z);
@@ -425,7 +476,12 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
                 const int pos = atomicAdd(a.fb_count, 1);
                 a.fb_list[pos] = gslot;
             }
+            DIAG_STAMP(5) // force / topology sort + outputs
         }
+    }
+    if (WTP_DIAG && (tid & 63) == 0) {
+        for (int i = 0; i < 6; ++i) atomicAdd(&a.diag[i], dt[i]);
+        atomicAdd(&a.diag[7], 1ull);
     }
     if (MODE == 1) {
         __syncthreads();

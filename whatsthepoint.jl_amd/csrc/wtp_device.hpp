@@ -185,7 +185,7 @@ __device__ inline Acc acc_empty() {
 __device__ inline void acc_point(Acc& acc, double force, double nn_dist, double s, int64_t id,
                                  int64_t nn) {
     acc.max_force = force > acc.max_force ? force : acc.max_force;
-    double u = nn_dist / s; // _dnn_cv term, src/repel.jl:380
+    double u = nn_dist / s; // _dnn_cv term, src/repel.jl:380 (callers pass the T-typed quotient when they have it)
     acc.sum_u += u;
     acc.sum_u2 += u * u;
     acc.n_move += 1;

@@ -110,6 +110,7 @@ template <typename T> struct SearchArgs {
     int32_t* fb2_count;
     // tunables
     T gamma_cap;               // initial filter radius cap, in cell edges
+    unsigned long long* diag;  // -DWTP_DIAG builds: per-phase wave-cycle sums (8 slots), else unused
 };
 
 // ---- device buffer with capacity -----------------------------------------------------------------
@@ -151,6 +152,7 @@ struct wtp_ctx {
     wtp::DevBuf forces, nn_dist, nn_id, spacing_pp;
     wtp::DevBuf partials, stats, fb_list, fb_count, fb2_list, fb2_count;
     wtp::DevBuf scratch;       // misc (relax_get staging, radius rows)
+    wtp::DevBuf diag;          // diagnostic builds only
     void* host_pinned = nullptr;
     size_t host_pinned_cap = 0;
     // radius two-phase state
