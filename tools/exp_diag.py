@@ -24,6 +24,6 @@ out = (C.c_ulonglong * 8)()
 lib.wtp_debug_diag(ctx._h, out)
 sess.run_async_free(3, 1)
 lib.wtp_debug_diag(ctx._h, out)
-names = ["stage", "query_setup", "scan", "select", "prune_compact", "force_out"]
-tot = sum(out[i] for i in range(6)) or 1
-print({names[i]: round(out[i] / tot, 4) for i in range(6)}, "waves", out[7], "cycles/wave", tot // max(out[7], 1))
+names = ["stage", "query_setup", "scan", "select", "prune_compact", "step_out", "force_loop"]
+tot = sum(out[i] for i in range(7)) or 1
+print({names[i]: round(out[i] / tot, 4) for i in range(7)}, "waves", out[7], "cycles/wave", tot // max(out[7], 1))

@@ -98,9 +98,16 @@ __device__ inline float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 
 // Sort this lane's ring keys (d2 recomputed from the staged points); return the k-th smallest
 // (index K-1) and the next one (index K).  KT > 0: K is the compile-time KT.
-template <int KT>
+struct NoVisit {
+    __device__ inline void operator()(const float4&, float, bool) const {}
+};
+
+// `visit(point, d2, valid)` sees every ring entry once while its point is in registers: the
+// sweep uses it to accumulate whatever does not depend on the cut (see SpecForce).
+template <int KT, class Visit>
 __device__ inline void ring_select(const float4* __restrict__ pts, const uint16_t* __restrict__ ring, int cnt,
-                                   float qx, float qy, float qz, int K, uint32_t& kth, uint32_t& next) {
+                                   float qx, float qy, float qz, int K, uint32_t& kth, uint32_t& next,
+                                   Visit& visit) {
     uint32_t k[NB];
 #pragma unroll
     for (int c8 = 0; c8 < NB / 8; ++c8) {
@@ -108,8 +115,10 @@ __device__ inline void ring_select(const float4* __restrict__ pts, const uint16_
 #pragma unroll
             for (int j = c8 * 8; j < c8 * 8 + 8; ++j) {
                 const float4 c = lds_pt(pts, ring[(j < cnt ? j : 0) * kBrickThreads]);
-                const uint32_t d = f2u(dist2<float>(qx, qy, qz, c.x, c.y, c.z));
+                const float df = dist2<float>(qx, qy, qz, c.x, c.y, c.z);
+                const uint32_t d = f2u(df);
                 k[j] = j < cnt ? d : 0x7F800000u;
+                visit(c, df, j < cnt);
             }
         } else {
 #pragma unroll
@@ -171,6 +180,42 @@ __device__ inline float force_fast(const ForceCoef& c, float u2) {
     const float f = (c.A - c.B * u2) * inv;
     return f > c.lo ? f : c.lo;
 }
+
+// Visitor of the sweep's final key pass.  Two things never depend on the k-th cut: the nearest
+// other point (always inside the k set for k >= 2), and — for ClippedSpacingForce, whose support
+// ends at u0*s — the force sum, as long as the support radius turns out to lie inside the cut
+// (then every point that contributes is one of the k nearest; the usual case: u0*s ~ h, r_k ~ 1.7 h).
+// The kernel checks that condition after the selection and otherwise runs the explicit loop.
+struct SpecForce {
+    float qx, qy, qz, inv_s2, lim;
+    int32_t qid;
+    ForceCoef fc;
+    bool on;           // wave-uniform: law is the clipped one
+    float Fx, Fy, Fz, nd2;
+    int32_t nid;
+    bool coincident;
+    __device__ inline void reset() {
+        Fx = Fy = Fz = 0.f;
+        nd2 = Lim<float>::inf();
+        nid = 0x7FFFFFFF;
+        coincident = false;
+    }
+    __device__ inline void operator()(const float4& c, float d, bool valid) {
+        if (!on) return;
+        const int32_t cid = w_to_id(c.w);
+        const bool in = valid && (cid != qid); // self skipped by index (src/repel.jl:271)
+        const bool nearer = in && lex_lt(d, cid, nd2, nid);
+        nd2 = nearer ? d : nd2;
+        nid = nearer ? cid : nid;
+        const bool act = in && (d <= lim);
+        const float f = force_fast(fc, d * inv_s2);
+        const float coef = (act && d > 0.f) ? f * __builtin_amdgcn_rsqf(d) : 0.f;
+        Fx += coef * (qx - c.x);
+        Fy += coef * (qy - c.y);
+        Fz += coef * (qz - c.z);
+        coincident = coincident || (act && !(d > 0.f));
+    }
+};
 
 template <int MODE, int KT>
 __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<float> a, int hcap) {
@@ -313,6 +358,20 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
             const int32_t skip_id = skip_self ? qid : -1; // ids are >= 0
             int cnt = 0;
             bool giveup = false;
+            // sweep: spacing at the query and the visitor that rides along the key pass
+            const float s = (MODE == 1) ? (a.spacing_pp ? a.spacing_pp[qid] : a.spacing_const) : 1.f;
+            SpecForce spec;
+            if (MODE == 1) {
+                spec.qx = qp.x;
+                spec.qy = qp.y;
+                spec.qz = qp.z;
+                spec.qid = qid;
+                spec.inv_s2 = 1.f / (s * s);
+                spec.lim = (a.u0 * a.u0) * (s * s);
+                spec.fc = force_coef(a.force_kind, a.beta, a.u0, a.gamma);
+                spec.on = (a.force_kind == WTP_FORCE_CLIPPED_SPACING) && (K >= 2) && !(WTP_ABL & 1);
+                spec.reset();
+            }
 
             // ---- scan / select loop: one instance of the network serves prunes and the final cut
             // LDS byte addresses: points at [0, hcap*16), this lane's ring row j at ring_b + j*512
@@ -372,7 +431,13 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
                     next = kth + 1;
                 } else {
                     DIAG_STAMP(2) // scan
-                    ring_select<KT>(pts, ring, cnt, qp.x, qp.y, qp.z, K, kth, next);
+                    if (MODE == 1) {
+                        spec.reset();
+                        ring_select<KT>(pts, ring, cnt, qp.x, qp.y, qp.z, K, kth, next, spec);
+                    } else {
+                        NoVisit nv;
+                        ring_select<KT>(pts, ring, cnt, qp.x, qp.y, qp.z, K, kth, next, nv);
+                    }
                     DIAG_STAMP(3) // select
                 }
                 if (!pressure) break;
@@ -416,20 +481,19 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
             } else {
                 if (!fallback) {
                     const float cut = u2f(kth);
-                    const float s = a.spacing_pp ? a.spacing_pp[qid] : a.spacing_const;
-                    const float inv_s2 = 1.f / (s * s);
-                    const float u0sq = a.u0 * a.u0;
+                    const float inv_s2 = spec.inv_s2;
                     // ClippedSpacingForce vanishes for u >= u0: neighbours beyond u0*s add nothing
-                    const float lim = (a.force_kind == WTP_FORCE_CLIPPED_SPACING && u0sq * (s * s) < cut)
-                                          ? u0sq * (s * s) : cut;
-                    const ForceCoef fc = force_coef(a.force_kind, a.beta, a.u0, a.gamma);
-                    bool coincident = false;
-                    float Fx = 0.f, Fy = 0.f, Fz = 0.f;
-                    int32_t nid = 0x7FFFFFFF;
-                    float nd2 = Lim<float>::inf();
-                    // 4 ring entries per step: offsets, then points, then branch-free math (the LDS
-                    // round trips are the cost here, so they are issued together)
-                    for (int j0 = 0; !(WTP_ABL & 1) && __any(j0 < cnt); j0 += 4) {
+                    const float lim = (a.force_kind == WTP_FORCE_CLIPPED_SPACING && spec.lim < cut) ? spec.lim : cut;
+                    const ForceCoef fc = spec.fc;
+                    // the key pass already summed everything when the law's support lies inside the cut
+                    const bool spec_ok = spec.on && (spec.lim <= cut);
+                    bool coincident = spec_ok ? spec.coincident : false;
+                    float Fx = spec_ok ? spec.Fx : 0.f, Fy = spec_ok ? spec.Fy : 0.f, Fz = spec_ok ? spec.Fz : 0.f;
+                    int32_t nid = spec_ok ? spec.nid : 0x7FFFFFFF;
+                    float nd2 = spec_ok ? spec.nd2 : Lim<float>::inf();
+                    // otherwise: explicit pass over the ring, 4 entries per step (offsets, then points,
+                    // then branch-free math; the LDS round trips are issued together)
+                    for (int j0 = 0; !(WTP_ABL & 1) && __any(!spec_ok && j0 < cnt); j0 += 4) {
                         uint16_t off[4];
                         float4 c[4];
 #pragma unroll
@@ -442,7 +506,7 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
                             const float d = (dx * dx + dy * dy) + dz * dz;
                             const int32_t cid = w_to_id(c[u].w);
                             // the kk nearest, self skipped by index (src/repel.jl:271)
-                            const bool in = ((j0 + u) < cnt) && (d <= cut) && (cid != qid);
+                            const bool in = !spec_ok && ((j0 + u) < cnt) && (d <= cut) && (cid != qid);
                             const bool nearer = in && lex_lt(d, cid, nd2, nid);
                             nd2 = nearer ? d : nd2;
                             nid = nearer ? cid : nid;
@@ -455,6 +519,7 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
                             coincident = coincident || (act && !(d > 0.f));
                         }
                     }
+                    DIAG_STAMP(6) // force loop
                     if (coincident) { // r == 0 needs the substitute direction: exact path (rare)
                         const int pos = atomicAdd(a.fb_count, 1);
                         a.fb_list[pos] = gslot;
@@ -480,7 +545,7 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
         }
     }
     if (WTP_DIAG && (tid & 63) == 0) {
-        for (int i = 0; i < 6; ++i) atomicAdd(&a.diag[i], dt[i]);
+        for (int i = 0; i < 7; ++i) atomicAdd(&a.diag[i], dt[i]);
         atomicAdd(&a.diag[7], 1ull);
     }
     if (MODE == 1) {
