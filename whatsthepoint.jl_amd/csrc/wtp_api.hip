@@ -206,6 +206,7 @@ WTP_API int wtp_create(const int* device_ordinals, int n_dev, wtp_ctx** out) {
     if (const char* e = getenv("WTP_RHO")) ctx->rho = atof(e) > 0 ? atof(e) : ctx->rho;
     if (const char* e = getenv("WTP_GAMMA_CAP")) ctx->gamma_cap = atof(e) > 0 ? atof(e) : ctx->gamma_cap;
     if (const char* e = getenv("WTP_FORCE_GENERIC")) ctx->force_generic = atoi(e);
+    if (const char* e = getenv("WTP_FULL_SELECT")) ctx->full_select = atoi(e);
     if (const char* e = getenv("WTP_TIMING")) ctx->timing = atoi(e) != 0;
     *out = ctx;
     return WTP_OK;

@@ -217,7 +217,7 @@ struct SpecForce {
     }
 };
 
-template <int MODE, int KT>
+template <int MODE, int KT, int CS>
 __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<float> a, int hcap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* pts = reinterpret_cast<float4*>(smem_raw);
@@ -372,6 +372,21 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
                 spec.on = (a.force_kind == WTP_FORCE_CLIPPED_SPACING) && (K >= 2) && !(WTP_ABL & 1);
                 spec.reset();
             }
+            // CS (compact support) sweep, ClippedSpacingForce only: the force sums over the k nearest
+            // points, but points beyond u0*s contribute exactly 0, so once
+            //   n_lim = #{points with d2 <= (u0 s)^2}  <=  k
+            // holds, those n_lim points ARE among the k nearest (everything else is farther) and the
+            // sum over them equals the reference's sum over its k-list — no selection needed.  The
+            // ring then only collects the support (plus a margin that always contains the nearest
+            // neighbour); queries where the count exceeds k, or whose support is not certified by the
+            // searched cells, go to the exact path.
+            bool cs_fail = false;
+            if (CS) {
+                const float tnn = (0.68f * g.c) * (0.68f * g.c);
+                const float tcs = spec.lim > tnn ? spec.lim : tnn;
+                cs_fail = !(spec.lim <= tau);
+                tau = tcs < tau ? tcs : tau;
+            }
 
             // ---- scan / select loop: one instance of the network serves prunes and the final cut
             // LDS byte addresses: points at [0, hcap*16), this lane's ring row j at ring_b + j*512
@@ -426,6 +441,13 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
                     }
                 }
                 cnt = (int)((ra - ring_b) / (kBrickThreads * 2u));
+                if (CS) { // no selection: everything within tau is in the ring
+                    giveup = giveup || pressure;
+                    kth = f2u(tau);
+                    next = ~0u;
+                    DIAG_STAMP(2) // scan
+                    break;
+                }
                 if (WTP_ABL & 2) {
                     kth = f2u(tau);
                     next = kth + 1;
@@ -455,7 +477,7 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
                 DIAG_STAMP(4) // prune compaction
             }
 
-            bool fallback = !WTP_ABL && ((cnt < K) || giveup || (kth == next)); // tie exactly at the cut -> exact path
+            bool fallback = !WTP_ABL && ((!CS && cnt < K) || giveup || cs_fail || (kth == next)); // tie at the cut -> exact path
             if (MODE == 0) {
                 if (!fallback) {
                     // survivors: exactly K entries with d2 <= cut; canonical order by 64-bit key
@@ -486,7 +508,8 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
                     const float lim = (a.force_kind == WTP_FORCE_CLIPPED_SPACING && spec.lim < cut) ? spec.lim : cut;
                     const ForceCoef fc = spec.fc;
                     // the key pass already summed everything when the law's support lies inside the cut
-                    const bool spec_ok = spec.on && (spec.lim <= cut);
+                    const bool spec_ok = !CS && spec.on && (spec.lim <= cut);
+                    int n_lim = 0; // CS: points (self included) inside the law's support
                     bool coincident = spec_ok ? spec.coincident : false;
                     float Fx = spec_ok ? spec.Fx : 0.f, Fy = spec_ok ? spec.Fy : 0.f, Fz = spec_ok ? spec.Fz : 0.f;
                     int32_t nid = spec_ok ? spec.nid : 0x7FFFFFFF;
@@ -511,6 +534,7 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
                             nd2 = nearer ? d : nd2;
                             nid = nearer ? cid : nid;
                             const bool act = in && (d <= lim);
+                            if (CS) n_lim += (((j0 + u) < cnt) && (d <= lim)) ? 1 : 0;
                             const float f = force_fast(fc, d * inv_s2);
                             const float coef = (act && d > 0.f) ? f * __builtin_amdgcn_rsqf(d) : 0.f;
                             Fx += coef * dx;
@@ -520,6 +544,7 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
                         }
                     }
                     DIAG_STAMP(6) // force loop
+                    if (CS && (n_lim > K || nid == 0x7FFFFFFF)) coincident = true; // not provable here: exact path
                     if (coincident) { // r == 0 needs the substitute direction: exact path (rare)
                         const int pos = atomicAdd(a.fb_count, 1);
                         a.fb_list[pos] = gslot;
@@ -562,14 +587,14 @@ static size_t brick_smem_bytes(int hcap) {
 // LDS budget: 160 KiB per CU; hcap sized so two workgroups fit.
 static int pick_hcap() { return 2560; }
 
-template <int MODE, int KT> static int brick_launch(wtp_ctx* ctx, SearchArgs<float>& a) {
+template <int MODE, int KT, int CS> static int brick_launch(wtp_ctx* ctx, SearchArgs<float>& a) {
     const int hcap = pick_hcap();
     static bool attr_set = false;
     static int occ = 0;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)brick_kernel<MODE, KT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)brick_kernel<MODE, KT, CS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)brick_smem_bytes(hcap));
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, brick_kernel<MODE, KT>, kBrickThreads,
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, brick_kernel<MODE, KT, CS>, kBrickThreads,
                                                                     brick_smem_bytes(hcap));
         if (e != hipSuccess || occ < 1) occ = 1;
         if (occ > 4) occ = 4;
@@ -578,7 +603,7 @@ template <int MODE, int KT> static int brick_launch(wtp_ctx* ctx, SearchArgs<flo
     int gsz = ctx->sm_count * occ;
     gsz -= gsz % 8;
     if (gsz < 8) gsz = 8;
-    hipLaunchKernelGGL((brick_kernel<MODE, KT>), dim3(gsz), dim3(kBrickThreads), brick_smem_bytes(hcap),
+    hipLaunchKernelGGL((brick_kernel<MODE, KT, CS>), dim3(gsz), dim3(kBrickThreads), brick_smem_bytes(hcap),
                        ctx->stream, a, hcap);
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;
@@ -590,7 +615,7 @@ template <> int launch_topology<float>(wtp_ctx* ctx, SearchArgs<float>& a) {
     if (a.k > kFastKMax - 1 || ctx->force_generic) return launch_generic_topology<float>(ctx, a, true);
     a.gamma_cap = (float)ctx->gamma_cap;
     WTP_HIP(ctx, hipMemsetAsync(a.fb_count, 0, sizeof(int32_t), ctx->stream));
-    int rc = a.k == 21 ? brick_launch<0, 21>(ctx, a) : brick_launch<0, 0>(ctx, a);
+    int rc = a.k == 21 ? brick_launch<0, 21, 0>(ctx, a) : brick_launch<0, 0, 0>(ctx, a);
     if (rc) return rc;
     return launch_generic_topology<float>(ctx, a, false);
 }
@@ -611,7 +636,11 @@ template <> int launch_sweep<float>(wtp_ctx* ctx, SearchArgs<float>& a, bool fre
     }
     a.gamma_cap = (float)ctx->gamma_cap;
     const int sp = span_begin(ctx, 1);
-    int rc = a.k == 21 ? brick_launch<1, 21>(ctx, a) : brick_launch<1, 0>(ctx, a);
+    // ClippedSpacingForce (the reference default) takes the compact-support sweep unless
+    // WTP_FULL_SELECT=1 asks for the explicit k-selection on every query (both give the same output)
+    const bool cs = a.force_kind == WTP_FORCE_CLIPPED_SPACING && a.k >= 2 && !ctx->full_select;
+    int rc = cs ? brick_launch<1, 0, 1>(ctx, a)
+                : (a.k == 21 ? brick_launch<1, 21, 0>(ctx, a) : brick_launch<1, 0, 0>(ctx, a));
     span_end(ctx, sp);
     if (rc) return rc;
     const int sp2 = span_begin(ctx, 2);

@@ -143,6 +143,7 @@ struct wtp_ctx {
     double rho = 8.0;
     double gamma_cap = 1.08;
     int force_generic = 0;
+    int full_select = 0;       // WTP_FULL_SELECT=1: never use the compact-support sweep
     // pooled device buffers
     wtp::DevBuf pts[3];        // Pt arrays
     wtp::DevBuf raw_in;        // AoS staging of host input

@@ -24,6 +24,7 @@ static constexpr int kThreads = kWaves * 64;
 static constexpr int kCap = 1024;            // candidates buffered per wave
 static constexpr int kKeyRegs = kCap / 64;
 static constexpr int kSurv = 256;            // survivors (d2 <= cut) ranked per wave
+static constexpr int kRowBatch = 8;          // rows whose first 64 points are loaded together
 
 template <typename T> struct Bits;
 template <> struct Bits<float> {
@@ -94,35 +95,62 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
             const int z0 = cz - r < 0 ? 0 : cz - r, z1 = cz + r > g.n[2] - 1 ? g.n[2] - 1 : cz + r;
             const int y0 = cy - r < 0 ? 0 : cy - r, y1 = cy + r > g.n[1] - 1 ? g.n[1] - 1 : cy + r;
             const int x0 = cx - r < 0 ? 0 : cx - r, x1 = cx + r > g.n[0] - 1 ? g.n[0] - 1 : cx + r;
-            for (int z = z0; z <= z1 && !overflow; ++z)
-                for (int y = y0; y <= y1 && !overflow; ++y) {
-                    const int row = (z * g.n[1] + y) * g.n[0];
-                    const int ps = a.cell_start[row + x0], pe = a.cell_start[row + x1 + 1];
-                    for (int p0 = ps; p0 < pe; p0 += 64) {
-                        const int p = p0 + lane;
-                        bool take = false;
-                        T d = 0;
-                        int32_t cid = 0;
-                        if (p < pe) {
-                            const Pt<T> c = a.snap[p];
-                            cid = w_to_id(c.w);
-                            d = dist2<T>(q.x, q.y, q.z, c.x, c.y, c.z);
-                            take = (d <= g2) && !(skip_self && cid == id);
-                        }
-                        const unsigned long long mask = __ballot(take);
-                        const int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
-                        if (take && pos < kCap) {
-                            sm->d2[pos] = d;
-                            sm->id[pos] = cid;
-                            sm->slot[pos] = p;
-                        }
-                        m += __popcll(mask);
-                        if (m > kCap) {
-                            overflow = true;
-                            break;
+            // Rows of the block are independent contiguous runs of the sorted array.  Lanes fetch
+            // the run bounds of up to 64 rows in one go; the first 64 points of kRowBatch rows are
+            // then loaded together (independent global loads in flight) before any is consumed.
+            auto consume = [&](int p, bool valid, const Pt<T>& c) {
+                bool take = false;
+                T d = 0;
+                int32_t cid = 0;
+                if (valid) {
+                    cid = w_to_id(c.w);
+                    d = dist2<T>(q.x, q.y, q.z, c.x, c.y, c.z);
+                    take = (d <= g2) && !(skip_self && cid == id);
+                }
+                const unsigned long long mask = __ballot(take);
+                const int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
+                if (take && pos < kCap) {
+                    sm->d2[pos] = d;
+                    sm->id[pos] = cid;
+                    sm->slot[pos] = p;
+                }
+                m += __popcll(mask);
+                if (m > kCap) overflow = true;
+            };
+            const int ny_rows = y1 - y0 + 1;
+            const int nrows = ny_rows * (z1 - z0 + 1);
+            for (int rb = 0; rb < nrows && !overflow; rb += 64) {
+                int my_ps = 0, my_pe = 0;
+                if (rb + lane < nrows) {
+                    const int i = rb + lane;
+                    const int row = ((z0 + i / ny_rows) * g.n[1] + (y0 + i % ny_rows)) * g.n[0];
+                    my_ps = a.cell_start[row + x0];
+                    my_pe = a.cell_start[row + x1 + 1];
+                }
+                const int nr = nrows - rb < 64 ? nrows - rb : 64;
+                for (int b = 0; b < nr && !overflow; b += kRowBatch) {
+                    Pt<T> c[kRowBatch];
+                    int ps[kRowBatch], pe[kRowBatch];
+#pragma unroll
+                    for (int u = 0; u < kRowBatch; ++u) {
+                        const int src = b + u < nr ? b + u : 0;
+                        ps[u] = __shfl(my_ps, src, 64);
+                        pe[u] = b + u < nr ? __shfl(my_pe, src, 64) : ps[u];
+                        const int p = ps[u] + lane;
+                        c[u] = a.snap[p < pe[u] ? p : ps[u] < a.n ? ps[u] : 0];
+                    }
+#pragma unroll
+                    for (int u = 0; u < kRowBatch; ++u) {
+                        if (overflow) break;
+                        consume(ps[u] + lane, ps[u] + lane < pe[u], c[u]);
+                        for (int p0 = ps[u] + 64; p0 < pe[u] && !overflow; p0 += 64) { // long rows
+                            const int p = p0 + lane;
+                            const Pt<T> cc = a.snap[p < pe[u] ? p : ps[u]];
+                            consume(p, p < pe[u], cc);
                         }
                     }
                 }
+            }
             if (overflow) break;
             if (m >= K) break;                       // everything inside g2 is known: the k-th is final
             if (g2 == Lim<T>::inf()) break;          // block covers the grid
