@@ -218,14 +218,15 @@ struct SpecForce {
 };
 
 template <int MODE, int KT, int CS>
-__global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<float> a, int hcap) {
+__global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(SearchArgs<float> a, int hcap) {
+    constexpr int nb = CS ? 32 : NB; // ring rows: the compact-support sweep keeps only the support
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* pts = reinterpret_cast<float4*>(smem_raw);
     uint16_t* ring_all = reinterpret_cast<uint16_t*>(smem_raw + (size_t)hcap * sizeof(float4) + kPadBytes);
     BrickSmem* sm = reinterpret_cast<BrickSmem*>(smem_raw + (size_t)hcap * sizeof(float4) + kPadBytes +
-                                                 (size_t)(NB + 1) * kBrickThreads * sizeof(uint16_t));
+                                                 (size_t)(nb + 1) * kBrickThreads * sizeof(uint16_t));
     const int tid = threadIdx.x;
-    uint16_t* ring = ring_all + tid; // entry j at ring[j * kBrickThreads]; row NB is a dump row
+    uint16_t* ring = ring_all + tid; // entry j at ring[j * kBrickThreads]; row nb is a dump row
 
     const Grid<float> g = *a.grid;
     const int K = KT > 0 ? KT : a.k;
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
     unsigned long long t_last = WTP_DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
     // masked-off ring reads use row 0: make every slot ever read from it a valid LDS point index
 #pragma unroll 1
-    for (int j = 0; j <= NB; ++j) ring[j * kBrickThreads] = 0;
+    for (int j = 0; j <= nb; ++j) ring[j * kBrickThreads] = 0;
 
     // XCD-aware brick order: blocks sharing blockIdx % 8 share an L2; give each such group one
     // contiguous slab of bricks so halo re-reads of neighbouring bricks hit that L2.
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
             // searched cells, go to the exact path.
             bool cs_fail = false;
             if (CS) {
-                const float tnn = (0.68f * g.c) * (0.68f * g.c);
+                const float tnn = (0.9f * g.c) * (0.9f * g.c); // < provable radius (>= c - c/256); holds the nearest neighbour
                 const float tcs = spec.lim > tnn ? spec.lim : tnn;
                 cs_fail = !(spec.lim <= tau);
                 tau = tcs < tau ? tcs : tau;
@@ -391,8 +392,8 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
             // ---- scan / select loop: one instance of the network serves prunes and the final cut
             // LDS byte addresses: points at [0, hcap*16), this lane's ring row j at ring_b + j*512
             const uint32_t ring_b = (uint32_t)hcap * 16u + (uint32_t)kPadBytes + (uint32_t)tid * 2u;
-            const uint32_t dump_b = ring_b + (uint32_t)NB * (kBrickThreads * 2u);
-            const uint32_t full_b = ring_b + (uint32_t)(NB - SCAN_U) * (kBrickThreads * 2u);
+            const uint32_t dump_b = ring_b + (uint32_t)nb * (kBrickThreads * 2u);
+            const uint32_t full_b = ring_b + (uint32_t)(nb - SCAN_U) * (kBrickThreads * 2u);
             uint32_t ra = ring_b; // next free ring entry
             const uint32_t lds_base = (uint32_t)(uintptr_t)smem_raw; // LDS byte address of the point area
             DIAG_STAMP(1) // query setup
@@ -442,7 +443,14 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
                 }
                 cnt = (int)((ra - ring_b) / (kBrickThreads * 2u));
                 if (CS) { // no selection: everything within tau is in the ring
-                    giveup = giveup || pressure;
+                    if (pressure) { // some lane's ring is full (dense cluster): only that lane gives up
+                        if (ra > full_b) {
+                            giveup = true;
+                            ra = ring_b;
+                            tau = -1.f;
+                        }
+                        continue; // resume the row scan
+                    }
                     kth = f2u(tau);
                     next = ~0u;
                     DIAG_STAMP(2) // scan
@@ -580,30 +588,30 @@ __global__ __launch_bounds__(kBrickThreads, 2) void brick_kernel(SearchArgs<floa
     }
 }
 
-static size_t brick_smem_bytes(int hcap) {
-    return (size_t)hcap * sizeof(float4) + kPadBytes + (size_t)(NB + 1) * kBrickThreads * sizeof(uint16_t) + sizeof(BrickSmem);
+static size_t brick_smem_bytes(int hcap, int nb) {
+    return (size_t)hcap * sizeof(float4) + kPadBytes + (size_t)(nb + 1) * kBrickThreads * sizeof(uint16_t) + sizeof(BrickSmem);
 }
 
-// LDS budget: 160 KiB per CU; hcap sized so two workgroups fit.
-static int pick_hcap() { return 2560; }
-
+// LDS budget: 160 KiB per CU.  Default point capacity 2560 (two workgroups per CU at rho ~ 8);
+// the caller may pass a smaller capacity when it knows the occupancy (compact-support sweep).
 template <int MODE, int KT, int CS> static int brick_launch(wtp_ctx* ctx, SearchArgs<float>& a) {
-    const int hcap = pick_hcap();
-    static bool attr_set = false;
+    const int nb = CS ? 32 : NB;
+    const int hcap = a.brick_hcap > 0 ? a.brick_hcap : 2560;
+    static int cached_hcap = -1;
     static int occ = 0;
-    if (!attr_set) {
+    if (cached_hcap != hcap) {
         (void)hipFuncSetAttribute((const void*)brick_kernel<MODE, KT, CS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)brick_smem_bytes(hcap));
+                                  (int)brick_smem_bytes(hcap, nb));
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, brick_kernel<MODE, KT, CS>, kBrickThreads,
-                                                                    brick_smem_bytes(hcap));
+                                                                    brick_smem_bytes(hcap, nb));
         if (e != hipSuccess || occ < 1) occ = 1;
         if (occ > 4) occ = 4;
-        attr_set = true;
+        cached_hcap = hcap;
     }
     int gsz = ctx->sm_count * occ;
     gsz -= gsz % 8;
     if (gsz < 8) gsz = 8;
-    hipLaunchKernelGGL((brick_kernel<MODE, KT, CS>), dim3(gsz), dim3(kBrickThreads), brick_smem_bytes(hcap),
+    hipLaunchKernelGGL((brick_kernel<MODE, KT, CS>), dim3(gsz), dim3(kBrickThreads), brick_smem_bytes(hcap, nb),
                        ctx->stream, a, hcap);
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;
@@ -638,7 +646,8 @@ template <> int launch_sweep<float>(wtp_ctx* ctx, SearchArgs<float>& a, bool fre
     const int sp = span_begin(ctx, 1);
     // ClippedSpacingForce (the reference default) takes the compact-support sweep unless
     // WTP_FULL_SELECT=1 asks for the explicit k-selection on every query (both give the same output)
-    const bool cs = a.force_kind == WTP_FORCE_CLIPPED_SPACING && a.k >= 2 && !ctx->full_select;
+    // (the caller sized the grid for it and says so by passing the LDS point capacity)
+    const bool cs = a.brick_hcap > 0 && a.force_kind == WTP_FORCE_CLIPPED_SPACING && a.k >= 2 && !ctx->full_select;
     int rc = cs ? brick_launch<1, 0, 1>(ctx, a)
                 : (a.k == 21 ? brick_launch<1, 21, 0>(ctx, a) : brick_launch<1, 0, 0>(ctx, a));
     span_end(ctx, sp);

@@ -79,7 +79,7 @@ __global__ void bbox_kernel(const Pt<T>* __restrict__ pts, int64_t n, T* __restr
 // One thread: final bbox reduce + grid parameters.  rho_k = target points per cell.
 template <typename T>
 __global__ void grid_setup_kernel(const T* __restrict__ part, int nparts, Grid<T>* __restrict__ g,
-                                  int64_t npts, int dim, double rho_k, double radius, int cell_cap) {
+                                  int64_t npts, int dim, double rho_k, double radius, double min_cell, int cell_cap) {
     // one wave: lanes stride over the per-block partials, shuffle-reduce, lane 0 does the setup
     double mn[3], mx[3];
     for (int a = 0; a < 3; ++a) {
@@ -116,6 +116,7 @@ __global__ void grid_setup_kernel(const T* __restrict__ part, int nparts, Grid<T
             double cc = pow(2.0 * vol / (double)npts, 1.0 / (double)dim);
             c = cr > cc ? cr : cc;
         }
+        if (radius <= 0 && min_cell > c) c = min_cell; // caller's floor on the cell edge
         if (!(c > 0)) c = emax;
     }
     int nn[3];
@@ -379,8 +380,11 @@ static int cell_capacity(const wtp_ctx* ctx, int64_t n, int k) {
 }
 
 template <typename T>
-int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, int k, double radius) {
-    const int cap = cell_capacity(ctx, n, radius > 0 ? 6 : k);
+int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, int k, double radius, double rho_direct,
+               double min_cell) {
+    // k-equivalent of the occupancy the caller fixed (rho = 8 <-> k = 21)
+    const int k_cap = rho_direct > 0 ? (int)(rho_direct * 21.0 / ctx->rho) : (radius > 0 ? 6 : k);
+    const int cap = cell_capacity(ctx, n, k_cap > 0 ? k_cap : 1);
     int rc;
     if ((rc = ensure(ctx, ctx->grid, sizeof(Grid<double>)))) return rc;
     const int nbb = grid_for(n, kThreads, 1024);
@@ -401,11 +405,12 @@ int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, in
 
     // target occupancy: c = 1.17 r_k  (r_k = k-th neighbour distance at uniform density)
     double rho_k = (dim == 3 ? 0.381 : 0.436) * (double)(k > 0 ? k : 21) * (ctx->rho / 8.0);
+    if (rho_direct > 0) rho_k = rho_direct; // caller fixes the occupancy (compact-support sweep)
     if (rho_k < 1.0) rho_k = 1.0;
 
     WTP_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)(cap + 1), st));
     hipLaunchKernelGGL(bbox_kernel<T>, dim3(nbb), dim3(kThreads), 0, st, in, n, part);
-    hipLaunchKernelGGL(grid_setup_kernel<T>, dim3(1), dim3(64), 0, st, part, nbb, g, n, dim, rho_k, radius, cap);
+    hipLaunchKernelGGL(grid_setup_kernel<T>, dim3(1), dim3(64), 0, st, part, nbb, g, n, dim, rho_k, radius, min_cell, cap);
     const int nb = grid_for(n, kThreads, 16384);
     hipLaunchKernelGGL(cell_rank_kernel<T>, dim3(nb), dim3(kThreads), 0, st, in, n, g, cnt, cr);
     hipLaunchKernelGGL(scan_reduce_kernel<T>, dim3(nscan), dim3(kThreads), 0, st, cnt, g, bs);
@@ -558,7 +563,7 @@ int launch_reduce_partials(wtp_ctx* ctx, const Partial* parts, int n_parts, cons
 // explicit instantiations
 #define INST(T)                                                                                         \
     template int load_points<T>(wtp_ctx*, const T*, Pt<T>*, int64_t, int);                              \
-    template int build_hash<T>(wtp_ctx*, const Pt<T>*, Pt<T>*, int64_t, int, int, double);              \
+    template int build_hash<T>(wtp_ctx*, const Pt<T>*, Pt<T>*, int64_t, int, int, double, double, double); \
     template int launch_unpermute<T>(wtp_ctx*, const Pt<T>*, int64_t, int64_t, int, T*);                \
     template int launch_unpermute_point_data<T>(wtp_ctx*, const Pt<T>*, int64_t, int64_t, const T*,    \
                                                 const T*, const int32_t*, T*, T*, int32_t*);            \

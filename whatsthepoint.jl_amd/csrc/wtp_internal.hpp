@@ -110,6 +110,7 @@ template <typename T> struct SearchArgs {
     int32_t* fb2_count;
     // tunables
     T gamma_cap;               // initial filter radius cap, in cell edges
+    int32_t brick_hcap;        // LDS point capacity for the brick kernel (0 = default)
     unsigned long long* diag;  // -DWTP_DIAG builds: per-phase wave-cycle sums (8 slots), else unused
 };
 
@@ -130,6 +131,9 @@ struct RelaxState {
     bool have_tree = false;
     bool can_revert = false;
     bool have_point_data = false;
+    double spacing_max = 0;  // largest spacing value (host-side max of the per-point array)
+    int brick_hcap = 0;      // LDS point capacity of the sweep's brick kernel (0 = not chosen yet)
+    bool cs_sweep = false;   // compact-support sweep in use (ClippedSpacingForce)
 };
 
 } // namespace wtp
@@ -195,7 +199,8 @@ void spans_collect(wtp_ctx* ctx);
 // hash build: from Pt array `in` (n points) produce sorted `out`, cell_start and the grid.
 // radius > 0 forces cell edge >= radius (RadiusTopology); k scales the target occupancy.
 template <typename T>
-int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, int k, double radius);
+int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, int k, double radius,
+               double rho_direct = 0.0, double min_cell = 0.0);
 
 template <typename T>
 int load_points(wtp_ctx* ctx, const T* d_xyz, Pt<T>* out, int64_t n, int dim);
