@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=10_000_000, help="points per GPU (weak scaling)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-full-select", action="store_true", help="skip the explicit k-selection leg")
     ap.add_argument("--cpu-points", type=int, default=4_000_000)
     ap.add_argument("--cpu-iters", type=int, default=6)
     args = ap.parse_args()
@@ -136,6 +137,37 @@ def main():
         dt = float(t.item())
     tm = ctx.timers()
 
+    # Same workload once more through the explicit k-selection path (WTP_FULL_SELECT=1: every query
+    # runs the 64-key network), N=1 only: the default path above certifies by counting that the
+    # k-list is not needed for ClippedSpacingForce; both produce the same step.
+    full_sel = None
+    if world == 1 and not args.no_full_select:
+        sess.close()
+        os.environ["WTP_FULL_SELECT"] = "1"
+        try:
+            ctx2 = wtp_amd.Context(local_rank)
+            xyz = torch.empty((n_local, 3), dtype=torch.float32, device="cuda")
+            ctx2.gen_uniform_dev(wtp_amd.synth.SEED, 0, n_local, 3, np.float32, xyz.data_ptr())
+            sess2 = ctx2.relax(None, 0, s, force, k, s / 2000, s / 20, device_ptr=(xyz.data_ptr(), n_local, 3, np.float32))
+            del xyz
+            sess2.run_async_free(args.warmup, 1)
+            ctx2.timers_reset()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            sess2.run_async_free(args.steps, 1)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            tm2 = ctx2.timers()
+            sw2 = tm2["sweep_ms"] / max(tm2["sweep_launches"], 1)
+            full_sel = {"value": round(n_local * args.steps / dt2 / 1e6, 3), "unit": "Mpoints/s",
+                        "ms_per_step": round(dt2 / args.steps * 1e3, 4), "sweep_ms": round(sw2, 4),
+                        "kernel": "wtp::brick_kernel<1,21,0> (64-key selection network on every query)",
+                        "roofline_frac": round(B_ALG_SWEEP * n_local / (sw2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+            sess2.close()
+            ctx2.close()
+        finally:
+            os.environ.pop("WTP_FULL_SELECT", None)
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = n_total * args.steps / dt / 1e6
@@ -165,7 +197,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "wtp::brick_kernel<1> (fused 27-cell k-NN + repel sweep)",
+                "kernel": "wtp::brick_kernel<1,0,1> (LDS-staged 27-cell sweep, count-certified k-set, fused repel force)",
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -189,6 +221,8 @@ def main():
             out["roofline"]["traffic"] = round(tj["traffic_bytes_per_launch"] * pts_per_launch / tj["points_per_launch"])
             out["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
             out["roofline"]["algorithmic_bytes"] = round(B_ALG_SWEEP * pts_per_launch)
+        if full_sel is not None:
+            out["full_k_selection_path"] = full_sel
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.cpu_points, args.cpu_iters)
         print(json.dumps(out), flush=True)

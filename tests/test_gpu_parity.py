@@ -207,3 +207,46 @@ def test_large_cloud_properties(ctx, wtp):
     for r in rows[:200]:
         d2 = ((x - x[r]) ** 2).sum(1)
         assert (d2 < np.float32(dist[r, -1]) ** 2 * (1 - 1e-6)).sum() - 1 <= k
+
+
+def test_compact_support_sweep_equals_full_selection(wtp, O):
+    """ClippedSpacingForce: the default compact-support sweep (count-certified, no k-selection) and
+    the explicit k-selection path (WTP_FULL_SELECT=1) must give the same step — both are the
+    reference's sum over the k nearest, the former just proves it does not need the list."""
+    import os
+
+    n = 60000
+    x = _cloud(wtp, n, 3, np.float32)
+    s, alo, amax = _sweep_args(n)
+    outs = {}
+    for mode in ("0", "1"):
+        os.environ["WTP_FULL_SELECT"] = mode
+        try:
+            with wtp.Context(0) as c, c.relax(x, 5000, s, FORCE, 21, alo, amax) as sess:
+                st = sess.step(True)
+                outs[mode] = (sess.positions(), sess.point_data(), st)
+        finally:
+            os.environ.pop("WTP_FULL_SELECT", None)
+    (p0, d0, s0), (p1, d1, s1) = outs["0"], outs["1"]
+    assert np.array_equal(d0["nn_id"], d1["nn_id"]) and np.array_equal(d0["nn_dist"], d1["nn_dist"])
+    assert np.abs(p0 - p1).max() <= 1e-5 * s          # same terms; the two grids scan (sum) in different orders
+    assert (p0 == p1).mean() > 0.9
+    assert s0["n_fallback"] < s1["n_fallback"]         # and it certifies far more queries locally
+    ref = O.relax_sweep(x, 5000, s, 2, 0.2, 1.0, 3.0, 21, alo, amax)
+    assert np.array_equal(d0["nn_id"], ref["nn_id"]) and np.abs(p0 - ref["p"]).max() <= 1e-5 * s
+
+
+def test_compact_support_dense_cluster_and_large_spacing(ctx, O, wtp):
+    # more than k points inside the law's support (dense cluster) and a spacing far above the
+    # mean distance: the count certificate must hand those queries to the exact path
+    n = 20000
+    x = _cloud(wtp, n, 3, np.float32)
+    x[3000:3400] = x[3000] + 2e-3 * (x[3000:3400] - 0.5)
+    for s in (float(n) ** (-1 / 3), 3.0 * float(n) ** (-1 / 3)):
+        with ctx.relax(x, 0, s, FORCE, 21, s / 2000, s / 20) as sess:
+            sess.step(True)
+            p = sess.positions()
+            pd = sess.point_data()
+        ref = O.relax_sweep(x, 0, s, 2, 0.2, 1.0, 3.0, 21, s / 2000, s / 20)
+        assert np.array_equal(pd["nn_id"], ref["nn_id"])
+        assert np.abs(p - ref["p"]).max() <= 2e-5 * s
