@@ -93,6 +93,18 @@ __device__ inline void lds_read_group(f4 (&c)[8], uint32_t addr) {
         : "memory");
 }
 
+__device__ inline void lds_read_group(f4 (&c)[4], uint32_t addr) {
+    asm volatile(
+        "ds_read_b128 %0, %4\n\t"
+        "ds_read_b128 %1, %4 offset:16\n\t"
+        "ds_read_b128 %2, %4 offset:32\n\t"
+        "ds_read_b128 %3, %4 offset:48\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3])
+        : "v"(addr)
+        : "memory");
+}
+
 __device__ inline uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 __device__ inline float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 
@@ -220,6 +232,9 @@ struct SpecForce {
 template <int MODE, int KT, int CS>
 __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(SearchArgs<float> a, int hcap) {
     constexpr int nb = CS ? 32 : NB; // ring rows: the compact-support sweep keeps only the support
+    // candidates per scan step: the compact-support grid has short runs (3 cells x ~3.5 points), where
+    // steps of 8 would spend half their slots past the run end
+    constexpr int SU = CS ? 4 : SCAN_U;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* pts = reinterpret_cast<float4*>(smem_raw);
     uint16_t* ring_all = reinterpret_cast<uint16_t*>(smem_raw + (size_t)hcap * sizeof(float4) + kPadBytes);
@@ -393,7 +408,7 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
             // LDS byte addresses: points at [0, hcap*16), this lane's ring row j at ring_b + j*512
             const uint32_t ring_b = (uint32_t)hcap * 16u + (uint32_t)kPadBytes + (uint32_t)tid * 2u;
             const uint32_t dump_b = ring_b + (uint32_t)nb * (kBrickThreads * 2u);
-            const uint32_t full_b = ring_b + (uint32_t)(nb - SCAN_U) * (kBrickThreads * 2u);
+            const uint32_t full_b = ring_b + (uint32_t)(nb - SU) * (kBrickThreads * 2u);
             uint32_t ra = ring_b; // next free ring entry
             const uint32_t lds_base = (uint32_t)(uintptr_t)smem_raw; // LDS byte address of the point area
             DIAG_STAMP(1) // query setup
@@ -417,10 +432,10 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
                             pressure = true;
                             break;
                         }
-                        f4 c[SCAN_U];
+                        f4 c[SU];
                         lds_read_group(c, lds_base + pa);
 #pragma unroll
-                        for (int u = 0; u < SCAN_U; ++u) {
+                        for (int u = 0; u < SU; ++u) {
                             const float d = dist2<float>(qp.x, qp.y, qp.z, c[u].x, c[u].y, c[u].z);
                             // run-end masking folded into the threshold (a VALU select) instead of
                             // and-ing lane masks on the scalar unit: no VALU->SALU->VALU round trip
@@ -430,7 +445,7 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
                             *reinterpret_cast<uint16_t*>(smem_raw + (take ? ra : dump_b)) = (uint16_t)(pa + 16u * u);
                             ra += take ? (kBrickThreads * 2u) : 0u;
                         }
-                        pa += 16u * SCAN_U;
+                        pa += 16u * SU;
                     }
                     if (pressure) break;
                     ++row;
