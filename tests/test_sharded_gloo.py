@@ -29,7 +29,7 @@ class OracleEngine:
         return torch.from_numpy(r["p"]), st
 
 
-def _worker(rank, world, port, n_total, iters, q):
+def _worker(rank, world, port, n_total, iters, q, margin=None):
     for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -43,11 +43,12 @@ def _worker(rank, world, port, n_total, iters, q):
     gen = lambda first, n: torch.from_numpy(wtp_amd.synth.uniform(n, 3, np.float32, 7, first))
     xyz, gid, cuts = sharded.uniform_shard(gen, rank, world, n_total, 7, "cpu", chunk=5000)
     drv = sharded.ShardedRelax(OracleEngine(s, k, s / 2000, s / 20), dist, xyz, gid, cuts,
-                               sharded.ghost_width(n_total, k))
+                               sharded.ghost_width(n_total, k), margin=margin)
     conv = [drv.step()["max_force"] for _ in range(iters)]
     allp = drv.gather_global(n_total)
     if rank == 0:
-        q.put((conv, allp.numpy(), [h["n_ghost"] for h in drv.history], [h["n_move"] for h in drv.history]))
+        q.put((conv, allp.numpy(), [h["n_ghost"] for h in drv.history], [h["n_move"] for h in drv.history],
+               drv.migrations))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -58,16 +59,18 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_matches_single_domain(O, wtp, world):
+@pytest.mark.parametrize("world,margin", [(2, None), (3, None), (2, 0.0), (3, 0.0)])
+def test_sharded_matches_single_domain(O, wtp, world, margin):
+    # margin=None: lazy migration (points may stray a quarter ghost width past a cut);
+    # margin=0: every crossing is handed over at once, so the migration path runs every iteration
     n_total, iters = 6000, 4
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, iters, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, iters, q, margin)) for r in range(world)]
     for p in procs:
         p.start()
-    conv, allp, n_ghost, n_move = q.get()
+    conv, allp, n_ghost, n_move, migrations = q.get()
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -78,6 +81,8 @@ def test_sharded_matches_single_domain(O, wtp, world):
     assert np.array_equal(allp, ref["p"])                      # decomposition-independent, bit for bit
     assert np.allclose(conv, ref["conv"], rtol=0, atol=0)
     assert all(g > 0 for g in n_ghost) and all(m == n_total for m in n_move)
+    if margin == 0.0:
+        assert migrations >= 1
 
 
 # ---- the same logic with the PRODUCT engine: 2 ranks sharing the one GPU of the test box, payloads

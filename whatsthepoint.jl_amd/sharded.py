@@ -36,6 +36,9 @@ class GpuEngine:
     def sweep(self, local_xyz: torch.Tensor, n_ghost: int):
         n = local_xyz.shape[0]
         out = torch.empty((n - n_ghost, 3), dtype=local_xyz.dtype, device=local_xyz.device)
+        # libwtp works on its own HIP stream: everything torch queued to build `local_xyz` must have
+        # finished before the library reads it (the library synchronises its stream before returning)
+        torch.cuda.current_stream(local_xyz.device).synchronize()
         sess = self.ctx.relax(None, n_ghost, self.spacing, self.force, self.k, self.alpha_lo, self.alpha_max,
                               device_ptr=(local_xyz.data_ptr(), n, 3, np.float32))
         try:
@@ -55,7 +58,7 @@ class ShardedRelax:
     """Owns this rank's points (positions + global ids) and runs sharded repel iterations."""
 
     def __init__(self, engine, dist, owned_xyz: torch.Tensor, owned_gid: torch.Tensor, cuts, ghost_width: float,
-                 rank: int = None, world: int = None, comm_device=None):
+                 rank: int = None, world: int = None, comm_device=None, margin: float = None):
         """comm_device: where collective payloads live — the points' own device for RCCL ("nccl"
         backend), "cpu" to stage through host memory when the backend is gloo (rehearsals with
         several ranks on one GPU)."""
@@ -67,6 +70,11 @@ class ShardedRelax:
         self.cdev = torch.device(comm_device) if comm_device is not None else self.dev
         self.cuts = torch.as_tensor(cuts, dtype=owned_xyz.dtype, device=self.dev).reshape(-1)
         self.w = float(ghost_width)
+        # lazy migration: an owned point may stray up to `margin` past a cut before it is handed
+        # over, so most iterations skip the compaction of the owned arrays; the ghost layer is
+        # widened by the same margin so that strays still see (and are seen by) their neighbours
+        self.margin = 0.25 * self.w if margin is None else float(margin)
+        self.migrations = 0
         self.last_local_points = int(owned_xyz.shape[0])
         self.history = []
 
@@ -105,9 +113,12 @@ class ShardedRelax:
         return from_lo.to(self.dev), m_from_lo, from_hi.to(self.dev), m_from_hi
 
     def _pack(self, mask):
-        gid = self.gid[mask]
+        return self._pack_rows(self.xyz[mask], self.gid[mask])
+
+    @staticmethod
+    def _pack_rows(xyz, gid):
         words = torch.stack([(gid & 0xFFFFFFFF).to(torch.int64), (gid >> 32).to(torch.int64)], 1).to(torch.int32)
-        return torch.cat([self.xyz[mask].view(torch.int32), words], 1)
+        return torch.cat([xyz.contiguous().view(torch.int32), words], 1)
 
     @staticmethod
     def _unpack(buf, dtype):
@@ -125,27 +136,39 @@ class ShardedRelax:
         lo, hi = self._bounds()
         if self.world > 1:
             z = self.xyz[:, 2]
-            # 1. who leaves (crossed a cut; |disp| <= s << slab) and who is ghost material
-            #    (stays mine, within w of a cut) — one exchange round carries both
-            go_lo, go_hi = z < lo, z >= hi
-            keep = ~(go_lo | go_hi)
-            gl_lo, gl_hi = keep & (z < lo + self.w), keep & (z >= hi - self.w)
-            mig_lo, mig_hi = self._pack(go_lo), self._pack(go_hi)
+            w_eff = self.w + self.margin
+            # 1. who leaves and who is ghost material — one exchange round carries both.  Points are
+            #    handed over only once one of them strays more than `margin` past a cut.
+            migrate = bool(((z < lo - self.margin) | (z >= hi + self.margin)).any())
+            if migrate:
+                self.migrations += 1
+                go_lo, go_hi = z < lo, z >= hi
+                keep = ~(go_lo | go_hi)
+                gl_lo, gl_hi = keep & (z < lo + w_eff), keep & (z >= hi - w_eff)
+            else:
+                go_lo = go_hi = torch.zeros(0, dtype=torch.bool, device=self.dev)
+                keep = None
+                gl_lo, gl_hi = z < lo + w_eff, z >= hi - w_eff
+            mig_lo = self._pack(go_lo) if migrate else self._pack_rows(self.xyz[:0], self.gid[:0])
+            mig_hi = self._pack(go_hi) if migrate else mig_lo
             from_lo, m_lo, from_hi, m_hi = self._exchange(
                 torch.cat([mig_lo, self._pack(gl_lo)]), int(mig_lo.shape[0]),
                 torch.cat([mig_hi, self._pack(gl_hi)]), int(mig_hi.shape[0]))
             # 2. ghosts = the neighbours' layers + my own emigrants (they now belong to a neighbour
             #    but sit within reach of my slab; the neighbour's layer was cut before they arrived)
-            gx = [self.xyz[go_lo], self.xyz[go_hi]]
-            parts_x, parts_g = [self.xyz[keep]], [self.gid[keep]]
+            gx = [self.xyz[go_lo], self.xyz[go_hi]] if migrate else []
+            parts_x, parts_g = ([self.xyz[keep]], [self.gid[keep]]) if migrate else ([self.xyz], [self.gid])
             for buf, m in ((from_lo, m_lo), (from_hi, m_hi)):
                 if buf.shape[0]:
                     x, g = self._unpack(buf, self.xyz.dtype)
                     parts_x.append(x[:m])
                     parts_g.append(g[:m])
                     gx.append(x[m:])
-            self.xyz, self.gid = torch.cat(parts_x), torch.cat(parts_g)
-            ghosts = torch.cat(gx)
+            if len(parts_x) > 1:
+                self.xyz, self.gid = torch.cat(parts_x), torch.cat(parts_g)
+            elif migrate:
+                self.xyz, self.gid = parts_x[0], parts_g[0]
+            ghosts = torch.cat(gx) if gx else self.xyz[:0]
         else:
             ghosts = self.xyz[:0]
         n_ghost = int(ghosts.shape[0])
