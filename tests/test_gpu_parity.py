@@ -250,3 +250,32 @@ def test_compact_support_dense_cluster_and_large_spacing(ctx, O, wtp):
         ref = O.relax_sweep(x, 0, s, 2, 0.2, 1.0, 3.0, 21, s / 2000, s / 20)
         assert np.array_equal(pd["nn_id"], ref["nn_id"])
         assert np.abs(p - ref["p"]).max() <= 2e-5 * s
+
+
+def _surface_cloud(n=46786, L=25.0, seed=5, dtype=np.float32):
+    """Stand-in for BASELINE config C1 (box.stl face centroids: 46 786 points on the faces of a
+    25^3 box; the STL itself does not travel to the GPU box): points on a 2-D manifold in 3-D,
+    i.e. cells along the faces are crowded and the interior is empty."""
+    rng = np.random.default_rng(seed)
+    p = rng.random((n, 3)) * L
+    f = rng.integers(0, 6, n)
+    p[np.arange(n), f % 3] = (f // 3) * L
+    return p.astype(dtype)
+
+
+def test_c1_surface_cloud_knn_and_sweep(ctx, O):
+    x = _surface_cloud()
+    idx, dist = ctx.knn(x, 21, include_self=False, return_dist=True)
+    oi, od = O.knn(x, 21, False, "kdtree")
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    idx = ctx.knn(x, 10, include_self=True)                                  # test/neighbors.jl:138-154 shapes
+    assert idx.shape == (len(x), 10) and (idx[:, 0] == np.arange(len(x))).all()
+    s = 25.0 / 8                                                             # _relative_spacing-like (coarse)
+    for sp in (0.3, s):
+        with ctx.relax(x, 20000, sp, FORCE, 21, sp / 2000, sp / 20) as sess:
+            sess.step(True)
+            p = sess.positions()
+            pd = sess.point_data()
+        ref = O.relax_sweep(x, 20000, sp, 2, 0.2, 1.0, 3.0, 21, sp / 2000, sp / 20)
+        assert np.array_equal(pd["nn_id"], ref["nn_id"])
+        assert np.abs(p - ref["p"]).max() <= 2e-5 * sp
