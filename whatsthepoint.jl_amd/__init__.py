@@ -13,6 +13,7 @@ from .forces import (RepelForceModel, InverseDistanceForce, SpacingEquilibriumFo
                      StrongSpacingForce, compute_force)
 from .spacings import ConstantSpacing, LogLike, BoundaryLayerSpacing
 from .repel import repel, relax
+from .metrics import metrics, spacing_metrics, spacing_fidelity_metrics
 from . import synth, stl
 
 __all__ = [n for n in dir() if not n.startswith("_")]
