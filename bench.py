@@ -115,7 +115,8 @@ def main():
         own_xyz, own_gid, cuts = sharded.uniform_shard(gen, rank, world, n_total, wtp_amd.synth.SEED, "cuda")
         drv = sharded.ShardedRelax(sharded.GpuEngine(ctx, s, force, k, s / 2000, s / 20), dist, own_xyz, own_gid, cuts,
                                    sharded.ghost_width(n_total, k, ctx_rho()),
-                                   comm_device="cpu" if rehearsal else None)
+                                   comm_device="cpu" if rehearsal else None,
+                                   legacy=os.environ.get("WTP_SHARD_LEGACY") == "1")
 
         def run(iters):
             drv.run(iters)
@@ -193,7 +194,8 @@ def main():
                             f"ClippedSpacingForce(beta=0.2), ConstantSpacing N^(-1/3), rebuild_every=1, "
                             f"stall_after=0, tol=0 (BASELINE.json configs[2])",
                 "points_per_gpu": n_local,
-                "sharding": "none" if world == 1 else f"{world} z-slabs + one-cell ghost exchange (RCCL)",
+                "sharding": "none" if world == 1 else f"{world} z-slabs, resident local sessions, ghost-layer exchange "
+                                                     f"per iteration (RCCL point-to-point)",
             },
             "roofline": {
                 "bound": "hbm",

@@ -169,6 +169,32 @@ int wtp_relax_set_spacing(wtp_ctx* ctx, const void* spacing);
 /* Release the relax state (device buffers stay pooled in the context). */
 int wtp_relax_end(wtp_ctx* ctx);
 
+/* ---- sharded sessions (no counterpart in the reference) --------------
+ * One rank sweeps one spatial slab.  Its session's fixed head is the ghost layer received
+ * from the neighbouring ranks, its movable tail the points it owns.  The two calls below
+ * keep such a session resident across iterations: only the layers cross the boundary.  */
+
+/* Run the library on a caller-owned HIP stream (e.g. the stream RCCL's results are ordered
+ * on) instead of the context's own: external = 1 lends hip_stream (NULL is the device's
+ * default stream), external = 0 restores the context's stream.  Device pointers handed to
+ * the *_dev entry points must be ready in the order of the stream in use.  */
+int wtp_set_stream(wtp_ctx* ctx, void* hip_stream, int external);
+
+/* Boundary layers of the movable points at their current positions, as packed 4-vectors
+ * {x, y, z, bits(movable index)} (dtype of the session) in device memory:
+ *   d_lo4  <- points with coord[axis] <  lo_in      counts[0]
+ *   d_hi4  <- points with coord[axis] >= hi_in      counts[1]
+ * and, counted only, the strays: coord < lo_out -> counts[2], coord >= hi_out -> counts[3].
+ * Order within a layer is deterministic (slot order of the last rebuild).  At most `cap`
+ * points are written per layer; counts report the true sizes.  */
+int wtp_relax_layers_dev(wtp_ctx* ctx, int axis, double lo_in, double hi_in, double lo_out, double hi_out,
+                         void* d_lo4, void* d_hi4, int64_t cap, int64_t counts[4]);
+
+/* Replace the fixed head of the snapshot by n_fixed_new points (packed 4-vectors in device
+ * memory, 4th component ignored).  Movable indices are unchanged; the next wtp_relax_step
+ * rebuilds.  Constant spacing only.  */
+int wtp_relax_set_fixed_dev(wtp_ctx* ctx, const void* d_fixed4, int64_t n_fixed_new);
+
 /* ---- measurement hooks (bench.py, profiles/) -------------------------------------- */
 
 /* Device time (ms, HIP events on the context's stream) spent in each phase since the

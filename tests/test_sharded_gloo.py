@@ -29,7 +29,36 @@ class OracleEngine:
         return torch.from_numpy(r["p"]), st
 
 
-def _worker(rank, world, port, n_total, iters, q, margin=None):
+class ResidentOracleEngine(OracleEngine):
+    """CPU stand-in for GpuEngine's resident protocol (open / layers / set_ghosts / step / positions)."""
+
+    resident = True
+
+    def open(self, xyz):
+        self.x = xyz.clone()
+        self.g = torch.zeros((0, 3), dtype=xyz.dtype)
+
+    def layers(self, axis, lo_in, hi_in, lo_out, hi_out):
+        v = self.x[:, axis]
+        rows = torch.cat([self.x.contiguous().view(torch.int32),
+                          torch.arange(len(v), dtype=torch.int32)[:, None]], 1)
+        return rows[v < lo_in], rows[v >= hi_in], int(((v < lo_out) | (v >= hi_out)).sum())
+
+    def set_ghosts(self, rows4):
+        self.g = rows4[:, :3].contiguous().view(torch.float32)
+
+    def step(self):
+        self.x, st = self.sweep(torch.cat([self.g, self.x]).contiguous(), len(self.g))
+        return st
+
+    def positions(self):
+        return self.x
+
+    def close(self):
+        pass
+
+
+def _worker(rank, world, port, n_total, iters, q, margin=None, resident=False):
     for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -42,8 +71,8 @@ def _worker(rank, world, port, n_total, iters, q, margin=None):
     s = float(n_total) ** (-1.0 / 3.0)
     gen = lambda first, n: torch.from_numpy(wtp_amd.synth.uniform(n, 3, np.float32, 7, first))
     xyz, gid, cuts = sharded.uniform_shard(gen, rank, world, n_total, 7, "cpu", chunk=5000)
-    drv = sharded.ShardedRelax(OracleEngine(s, k, s / 2000, s / 20), dist, xyz, gid, cuts,
-                               sharded.ghost_width(n_total, k), margin=margin)
+    eng = (ResidentOracleEngine if resident else OracleEngine)(s, k, s / 2000, s / 20)
+    drv = sharded.ShardedRelax(eng, dist, xyz, gid, cuts, sharded.ghost_width(n_total, k), margin=margin)
     conv = [drv.step()["max_force"] for _ in range(iters)]
     allp = drv.gather_global(n_total)
     if rank == 0:
@@ -59,15 +88,17 @@ def _free_port():
         return s.getsockname()[1]
 
 
+@pytest.mark.parametrize("resident", [False, True])
 @pytest.mark.parametrize("world,margin", [(2, None), (3, None), (2, 0.0), (3, 0.0)])
-def test_sharded_matches_single_domain(O, wtp, world, margin):
+def test_sharded_matches_single_domain(O, wtp, world, margin, resident):
     # margin=None: lazy migration (points may stray a quarter ghost width past a cut);
     # margin=0: every crossing is handed over at once, so the migration path runs every iteration
     n_total, iters = 6000, 4
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, iters, q, margin)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, iters, q, margin, resident))
+             for r in range(world)]
     for p in procs:
         p.start()
     conv, allp, n_ghost, n_move, migrations = q.get()

@@ -64,6 +64,9 @@ SIGNATURES = {
     "wtp_relax_revert": (_i, [_vp]),
     "wtp_relax_set_spacing": (_i, [_vp, _vp]),
     "wtp_relax_end": (_i, [_vp]),
+    "wtp_set_stream": (_i, [_vp, _vp, _i]),
+    "wtp_relax_layers_dev": (_i, [_vp, _i, _d, _d, _d, _d, _vp, _vp, _i64, C.POINTER(_i64)]),
+    "wtp_relax_set_fixed_dev": (_i, [_vp, _vp, _i64]),
     "wtp_timers_get": (_i, [_vp, C.POINTER(_d)]),
     "wtp_timers_reset": (_i, [_vp]),
     "wtp_gen_uniform_dev": (_i, [_vp, C.c_uint64, _i64, _i64, _i, _i, _vp]),
@@ -92,6 +95,13 @@ def load():
             f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
         )
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64 and a process
+    # that maps the system copy first (through libwtp) leaves torch without devices ("No HIP GPUs
+    # are available", observed).  Mapping torch's copy first makes both sides share it.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(SO_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol

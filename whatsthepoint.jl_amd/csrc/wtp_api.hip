@@ -212,10 +212,11 @@ WTP_API int wtp_create(const int* device_ordinals, int n_dev, wtp_ctx** out) {
     wtp_ctx* ctx = new wtp_ctx();
     ctx->device = dev;
     ctx->sm_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return fail(nullptr, WTP_ERR_HIP, "hipStreamCreate failed");
     }
+    ctx->stream = ctx->own_stream;
     if (const char* e = getenv("WTP_RHO")) ctx->rho = atof(e) > 0 ? atof(e) : ctx->rho;
     if (const char* e = getenv("WTP_GAMMA_CAP")) ctx->gamma_cap = atof(e) > 0 ? atof(e) : ctx->gamma_cap;
     if (const char* e = getenv("WTP_FORCE_GENERIC")) ctx->force_generic = atoi(e);
@@ -238,7 +239,7 @@ WTP_API int wtp_destroy(wtp_ctx* ctx) {
         if (b->p) hipFree(b->p);
     if (ctx->host_pinned) hipHostFree(ctx->host_pinned);
     for (auto e : ctx->ev_pool) hipEventDestroy(e);
-    hipStreamDestroy(ctx->stream);
+    hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return WTP_OK;
 }
@@ -446,6 +447,7 @@ static int relax_init_impl(wtp_ctx* ctx, const void* snap_xyz, bool on_device, i
     r.dim = dim;
     r.dtype = dtype;
     r.k = kk;
+    r.k_req = k;
     r.spacing_kind = spacing->kind;
     r.spacing_const = spacing->constant;
     r.spacing_max = spacing->constant;
@@ -727,6 +729,86 @@ WTP_API int wtp_relax_end(wtp_ctx* ctx) {
     if (!ctx) return WTP_ERR_ARG;
     ctx->relax = RelaxState{};
     return WTP_OK;
+}
+
+// ---- sharded sessions ---------------------------------------------------------------------------------
+WTP_API int wtp_set_stream(wtp_ctx* ctx, void* hip_stream, int external) {
+    if (!ctx) return WTP_ERR_ARG;
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    spans_collect(ctx); // events of open spans belong to the old stream
+    WTP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = external ? (hipStream_t)hip_stream : ctx->own_stream;
+    return WTP_OK;
+}
+
+WTP_API int wtp_relax_layers_dev(wtp_ctx* ctx, int axis, double lo_in, double hi_in, double lo_out, double hi_out,
+                                 void* d_lo4, void* d_hi4, int64_t cap, int64_t counts[4]) {
+    if (!ctx) return WTP_ERR_ARG;
+    RelaxState& r = ctx->relax;
+    if (!r.active) return fail(ctx, WTP_ERR_STATE, "wtp_relax_layers_dev before wtp_relax_init");
+    if (axis < 0 || axis >= r.dim) return fail(ctx, WTP_ERR_ARG, "axis must be in [0, dim)");
+    if (cap < 0 || (cap > 0 && (!d_lo4 || !d_hi4))) return fail(ctx, WTP_ERR_ARG, "layer buffers are NULL");
+    if (!counts) return fail(ctx, WTP_ERR_ARG, "counts is NULL");
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    const int nblk = layer_blocks(r.n);
+    if ((rc = ensure(ctx, ctx->scratch, 64 + sizeof(int2) * (size_t)nblk))) return rc;
+    int32_t* d_tot = (int32_t*)ctx->scratch.p;
+    int2* d_blk = (int2*)((char*)ctx->scratch.p + 64);
+    if (r.dtype == WTP_F32)
+        rc = launch_layers<float>(ctx, (const float4*)ctx->pts[r.bufP].p, r.n, r.n_fixed, axis, lo_in, hi_in, lo_out,
+                                  hi_out, (float4*)d_lo4, (float4*)d_hi4, cap, d_blk, d_tot);
+    else
+        rc = launch_layers<double>(ctx, (const double4*)ctx->pts[r.bufP].p, r.n, r.n_fixed, axis, lo_in, hi_in, lo_out,
+                                   hi_out, (double4*)d_lo4, (double4*)d_hi4, cap, d_blk, d_tot);
+    if (rc) return rc;
+    if ((rc = ensure_pinned(ctx, 64))) return rc;
+    WTP_HIP(ctx, hipMemcpyAsync(ctx->host_pinned, d_tot, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = sync(ctx))) return rc;
+    for (int j = 0; j < 4; ++j) counts[j] = ((const int32_t*)ctx->host_pinned)[j];
+    return WTP_OK;
+}
+
+WTP_API int wtp_relax_set_fixed_dev(wtp_ctx* ctx, const void* d_fixed4, int64_t n_fixed_new) {
+    if (!ctx) return WTP_ERR_ARG;
+    RelaxState& r = ctx->relax;
+    if (!r.active) return fail(ctx, WTP_ERR_STATE, "wtp_relax_set_fixed_dev before wtp_relax_init");
+    if (r.spacing_kind != WTP_SPACING_CONSTANT)
+        return fail(ctx, WTP_ERR_STATE, "wtp_relax_set_fixed_dev needs a constant spacing");
+    if (n_fixed_new < 0 || (n_fixed_new > 0 && !d_fixed4)) return fail(ctx, WTP_ERR_ARG, "bad fixed-point array");
+    const int64_t n_move = r.n - r.n_fixed, n_new = n_move + n_fixed_new;
+    if (n_new < 1) return fail(ctx, WTP_ERR_ARG, "the snapshot would be empty");
+    if (n_new > 2000000000LL) return fail(ctx, WTP_ERR_ARG, "n exceeds the int32 index space");
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t ts = tsize(r.dtype);
+    const size_t ptsz = r.dtype == WTP_F32 ? sizeof(float4) : sizeof(double4);
+    int rc;
+    const int t = pick_free(r, r.bufP, -1);
+    if ((rc = ensure(ctx, ctx->pts[t], ptsz * (size_t)n_new))) return rc;
+    if ((rc = ensure(ctx, ctx->forces, ts * (size_t)n_new))) return rc;
+    if ((rc = ensure(ctx, ctx->nn_dist, ts * (size_t)n_new))) return rc;
+    if ((rc = ensure(ctx, ctx->nn_id, sizeof(int32_t) * (size_t)n_new))) return rc;
+    if ((rc = ensure(ctx, ctx->fb_list, sizeof(int32_t) * (size_t)n_new))) return rc;
+    if ((rc = ensure(ctx, ctx->fb2_list, sizeof(int32_t) * (size_t)n_new))) return rc;
+    if ((rc = ensure(ctx, ctx->scratch, 64))) return rc;
+    if (r.dtype == WTP_F32)
+        rc = launch_refix<float>(ctx, (const float4*)ctx->pts[r.bufP].p, r.n, r.n_fixed, n_fixed_new,
+                                 (const float4*)d_fixed4, (float4*)ctx->pts[t].p, (int32_t*)ctx->scratch.p);
+    else
+        rc = launch_refix<double>(ctx, (const double4*)ctx->pts[r.bufP].p, r.n, r.n_fixed, n_fixed_new,
+                                  (const double4*)d_fixed4, (double4*)ctx->pts[t].p, (int32_t*)ctx->scratch.p);
+    if (rc) return rc;
+    r.n = n_new;
+    r.n_fixed = n_fixed_new;
+    r.k = (int64_t)r.k_req < n_new ? r.k_req : (int)n_new;
+    r.bufP = t;
+    r.bufS = -1;
+    r.bufOld = -1;
+    r.have_tree = false;
+    r.can_revert = false;
+    r.have_point_data = false;
+    // the caller's array must outlive the copy: on a lent stream that is stream order, else wait
+    return ctx->stream == ctx->own_stream ? sync(ctx) : WTP_OK;
 }
 
 WTP_API int wtp_timers_get(wtp_ctx* ctx, double out[4]) {

@@ -560,8 +560,230 @@ int launch_reduce_partials(wtp_ctx* ctx, const Partial* parts, int n_parts, cons
     return WTP_OK;
 }
 
+// ---- sharded sessions: boundary layers out, ghost layer in ----------------------
+// Ordered compaction in two launches.  A block owns kLayerChunk consecutive slots; the output order
+// is (block, wave, pass, lane) — a fixed function of the slot order, so the layer a neighbour
+// receives (and with it the ids its ghosts get) does not depend on scheduling.
+static constexpr int kLayerPasses = 32;
+static constexpr int kLayerChunk = kThreads * kLayerPasses;
+
+int layer_blocks(int64_t n) { return (int)((n + kLayerChunk - 1) / kLayerChunk); }
+
+template <typename T> __device__ inline T axis_of(const Pt<T>& p, int axis) {
+    return axis == 0 ? p.x : (axis == 1 ? p.y : p.z);
+}
+
+// slot of (wave, pass, lane) inside a block's chunk: a wave reads 64 consecutive points per pass
+__device__ inline int64_t layer_slot(int block, int wave, int pass, int lane) {
+    return (int64_t)block * kLayerChunk + ((int64_t)wave * kLayerPasses + pass) * 64 + lane;
+}
+
+template <typename T>
+__global__ void layer_count_kernel(const Pt<T>* __restrict__ pts, int64_t n, int32_t n_fixed, int axis, T lo_in,
+                                   T hi_in, T lo_out, T hi_out, int2* __restrict__ blk, int32_t* __restrict__ totals) {
+    __shared__ int sm[4][kThreads / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int c[4] = {0, 0, 0, 0};
+    for (int pass = 0; pass < kLayerPasses; ++pass) {
+        const int64_t i = layer_slot(blockIdx.x, wave, pass, lane);
+        bool in_lo = false, in_hi = false, out_lo = false, out_hi = false;
+        if (i < n) {
+            const Pt<T> p = pts[i];
+            if (w_to_id(p.w) >= n_fixed) {
+                const T v = axis_of<T>(p, axis);
+                in_lo = v < lo_in;
+                in_hi = v >= hi_in;
+                out_lo = v < lo_out;
+                out_hi = v >= hi_out;
+            }
+        }
+        c[0] += __popcll(__ballot(in_lo));
+        c[1] += __popcll(__ballot(in_hi));
+        c[2] += __popcll(__ballot(out_lo));
+        c[3] += __popcll(__ballot(out_hi));
+    }
+    if (lane == 0)
+        for (int j = 0; j < 4; ++j) sm[j][wave] = c[j];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t[4] = {0, 0, 0, 0};
+        for (int j = 0; j < 4; ++j)
+            for (int w = 0; w < kThreads / 64; ++w) t[j] += sm[j][w];
+        blk[blockIdx.x] = make_int2(t[0], t[1]);
+        for (int j = 0; j < 4; ++j)
+            if (t[j]) atomicAdd(&totals[j], t[j]);
+    }
+}
+
+template <typename T>
+__global__ void layer_fill_kernel(const Pt<T>* __restrict__ pts, int64_t n, int32_t n_fixed, int axis, T lo_in,
+                                  T hi_in, const int2* __restrict__ blk, Pt<T>* __restrict__ out_lo,
+                                  Pt<T>* __restrict__ out_hi, int64_t cap) {
+    __shared__ int sm_base[2][kThreads / 64];
+    __shared__ int sm_wave[2][kThreads / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blk[blockIdx.x].x == 0 && blk[blockIdx.x].y == 0) return; // nothing of this chunk is in a layer
+    // exclusive prefix of the block counts before this block
+    int b0 = 0, b1 = 0;
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += kThreads) {
+        const int2 v = blk[j];
+        b0 += v.x;
+        b1 += v.y;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        b0 += __shfl_down(b0, d, 64);
+        b1 += __shfl_down(b1, d, 64);
+    }
+    if (lane == 0) {
+        sm_base[0][wave] = b0;
+        sm_base[1][wave] = b1;
+    }
+    // this wave's own counts (same predicate as the count kernel)
+    int c0 = 0, c1 = 0;
+    for (int pass = 0; pass < kLayerPasses; ++pass) {
+        const int64_t i = layer_slot(blockIdx.x, wave, pass, lane);
+        bool in_lo = false, in_hi = false;
+        if (i < n) {
+            const Pt<T> p = pts[i];
+            if (w_to_id(p.w) >= n_fixed) {
+                const T v = axis_of<T>(p, axis);
+                in_lo = v < lo_in;
+                in_hi = v >= hi_in;
+            }
+        }
+        c0 += __popcll(__ballot(in_lo));
+        c1 += __popcll(__ballot(in_hi));
+    }
+    if (lane == 0) {
+        sm_wave[0][wave] = c0;
+        sm_wave[1][wave] = c1;
+    }
+    __syncthreads();
+    int64_t pos0 = 0, pos1 = 0;
+    for (int w = 0; w < kThreads / 64; ++w) {
+        pos0 += sm_base[0][w];
+        pos1 += sm_base[1][w];
+        if (w < wave) {
+            pos0 += sm_wave[0][w];
+            pos1 += sm_wave[1][w];
+        }
+    }
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int pass = 0; pass < kLayerPasses; ++pass) {
+        const int64_t i = layer_slot(blockIdx.x, wave, pass, lane);
+        bool in_lo = false, in_hi = false;
+        Pt<T> p{};
+        if (i < n) {
+            p = pts[i];
+            const int32_t id = w_to_id(p.w);
+            if (id >= n_fixed) {
+                const T v = axis_of<T>(p, axis);
+                in_lo = v < lo_in;
+                in_hi = v >= hi_in;
+                p.w = id_to_w((T)0, id - n_fixed);
+            }
+        }
+        const unsigned long long m0 = __ballot(in_lo), m1 = __ballot(in_hi);
+        if (in_lo) {
+            const int64_t o = pos0 + __popcll(m0 & below);
+            if (o < cap) out_lo[o] = p;
+        }
+        if (in_hi) {
+            const int64_t o = pos1 + __popcll(m1 & below);
+            if (o < cap) out_hi[o] = p;
+        }
+        pos0 += __popcll(m0);
+        pos1 += __popcll(m1);
+    }
+}
+
+template <typename T>
+int launch_layers(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int64_t n_fixed, int axis, double lo_in, double hi_in,
+                  double lo_out, double hi_out, Pt<T>* d_lo, Pt<T>* d_hi, int64_t cap, int2* d_blk, int32_t* d_totals) {
+    const int nblk = layer_blocks(n);
+    WTP_HIP(ctx, hipMemsetAsync(d_totals, 0, 4 * sizeof(int32_t), ctx->stream));
+    hipLaunchKernelGGL(layer_count_kernel<T>, dim3(nblk), dim3(kThreads), 0, ctx->stream, pts, n, (int32_t)n_fixed, axis,
+                       (T)lo_in, (T)hi_in, (T)lo_out, (T)hi_out, d_blk, d_totals);
+    hipLaunchKernelGGL(layer_fill_kernel<T>, dim3(nblk), dim3(kThreads), 0, ctx->stream, pts, n, (int32_t)n_fixed, axis,
+                       (T)lo_in, (T)hi_in, (const int2*)d_blk, d_lo, d_hi, cap);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
+// New snapshot = [new fixed head (ids 0..n_fixed_new) ; movable points of `in` with ids shifted].
+// Movable points are appended through a counter, one atomic per block of kRefixChunk slots (a
+// per-wave atomic on the single counter serialises: 1.8 ms at 12 M points, measured): their order
+// in `out` is arbitrary, the counting sort that follows (and its per-cell canonical order)
+// removes it.
+static constexpr int kRefixPasses = 8;
+static constexpr int kRefixChunk = kThreads * kRefixPasses;
+
+template <typename T>
+__global__ void refix_kernel(const Pt<T>* __restrict__ in, int64_t n_old, int32_t n_fixed_old, int32_t n_fixed_new,
+                             const Pt<T>* __restrict__ fixed_new, Pt<T>* __restrict__ out,
+                             int32_t* __restrict__ counter, int n_chunks) {
+    __shared__ int sm_wave[kThreads / 64];
+    __shared__ int sm_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    if ((int)blockIdx.x < n_chunks) {
+        Pt<T> p[kRefixPasses];
+        unsigned long long m[kRefixPasses];
+        int total = 0;
+#pragma unroll
+        for (int pass = 0; pass < kRefixPasses; ++pass) {
+            const int64_t i = (int64_t)blockIdx.x * kRefixChunk + (int64_t)pass * kThreads + threadIdx.x;
+            bool keep = false;
+            if (i < n_old) {
+                p[pass] = in[i];
+                const int32_t id = w_to_id(p[pass].w);
+                keep = id >= n_fixed_old;
+                p[pass].w = id_to_w((T)0, id - n_fixed_old + n_fixed_new);
+            }
+            m[pass] = __ballot(keep);
+            total += __popcll(m[pass]);
+        }
+        if (lane == 0) sm_wave[wave] = total;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (int w = 0; w < kThreads / 64; ++w) t += sm_wave[w];
+            sm_base = t ? atomicAdd(counter, t) : 0;
+        }
+        __syncthreads();
+        int64_t pos = (int64_t)n_fixed_new + sm_base;
+        for (int w = 0; w < wave; ++w) pos += sm_wave[w];
+#pragma unroll
+        for (int pass = 0; pass < kRefixPasses; ++pass) {
+            if ((m[pass] >> lane) & 1ull) out[pos + __popcll(m[pass] & below)] = p[pass];
+            pos += __popcll(m[pass]);
+        }
+    }
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_fixed_new; j += stride) {
+        Pt<T> q = fixed_new[j];
+        q.w = id_to_w((T)0, (int32_t)j);
+        out[j] = q;
+    }
+}
+
+template <typename T>
+int launch_refix(wtp_ctx* ctx, const Pt<T>* in, int64_t n_old, int64_t n_fixed_old, int64_t n_fixed_new,
+                 const Pt<T>* d_fixed_new, Pt<T>* out, int32_t* d_counter) {
+    WTP_HIP(ctx, hipMemsetAsync(d_counter, 0, sizeof(int32_t), ctx->stream));
+    const int n_chunks = (int)((n_old + kRefixChunk - 1) / kRefixChunk);
+    const int blocks = n_chunks > 1024 ? n_chunks : 1024; // >= 1024 so the head copy also fills the chip
+    hipLaunchKernelGGL(refix_kernel<T>, dim3(blocks), dim3(kThreads), 0, ctx->stream, in, n_old, (int32_t)n_fixed_old,
+                       (int32_t)n_fixed_new, d_fixed_new, out, d_counter, n_chunks);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
 // explicit instantiations
 #define INST(T)                                                                                         \
+    template int launch_layers<T>(wtp_ctx*, const Pt<T>*, int64_t, int64_t, int, double, double, double, double, \
+                                  Pt<T>*, Pt<T>*, int64_t, int2*, int32_t*);                            \
+    template int launch_refix<T>(wtp_ctx*, const Pt<T>*, int64_t, int64_t, int64_t, const Pt<T>*, Pt<T>*, int32_t*); \
     template int load_points<T>(wtp_ctx*, const T*, Pt<T>*, int64_t, int);                              \
     template int build_hash<T>(wtp_ctx*, const Pt<T>*, Pt<T>*, int64_t, int, int, double, double, double); \
     template int launch_unpermute<T>(wtp_ctx*, const Pt<T>*, int64_t, int64_t, int, T*);                \

@@ -124,6 +124,7 @@ struct RelaxState {
     bool active = false;
     int64_t n = 0, n_fixed = 0;
     int dim = 3, dtype = 0, k = 0;
+    int k_req = 0;           // k as requested (k = min(k_req, n) follows n when the fixed head is swapped)
     int spacing_kind = 0;
     double spacing_const = 0, alpha_lo = 0, alpha_max = 0;
     ForceParams force{};
@@ -140,7 +141,8 @@ struct RelaxState {
 
 struct wtp_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;     // the stream every launch goes to
+    hipStream_t own_stream = nullptr; // created with the context; `stream` unless wtp_set_stream lent another
     std::string err;
     int sm_count = 256;
     // tunables (env WTP_RHO / WTP_GAMMA_CAP / WTP_FORCE_GENERIC)
@@ -233,5 +235,13 @@ template <typename T>
 int launch_set_point(wtp_ctx* ctx, Pt<T>* pts, int64_t n, int32_t id, int dim, const T* d_xyz3);
 template <typename T>
 int launch_gen_uniform(wtp_ctx* ctx, uint64_t seed, int64_t first, int64_t n, int dim, T* d_out);
+// sharded sessions: boundary layers of the movable points / replacement of the fixed head
+int layer_blocks(int64_t n);
+template <typename T>
+int launch_layers(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int64_t n_fixed, int axis, double lo_in, double hi_in,
+                  double lo_out, double hi_out, Pt<T>* d_lo, Pt<T>* d_hi, int64_t cap, int2* d_blk, int32_t* d_totals);
+template <typename T>
+int launch_refix(wtp_ctx* ctx, const Pt<T>* in, int64_t n_old, int64_t n_fixed_old, int64_t n_fixed_new,
+                 const Pt<T>* d_fixed_new, Pt<T>* out, int32_t* d_counter);
 
 } // namespace wtp

@@ -103,6 +103,12 @@ class Context:
     def relax(self, snap, n_fixed: int, spacing, force, k: int, alpha_lo: float, alpha_max: float, device_ptr=None):
         return RelaxSession(self, snap, n_fixed, spacing, force, k, alpha_lo, alpha_max, device_ptr=device_ptr)
 
+    def set_stream(self, stream_handle=None):
+        """Run the library on a caller-owned HIP stream (handle as an int; 0 = the device's default
+        stream, which is torch's current stream unless the caller switched); None = own stream."""
+        ext = stream_handle is not None
+        L.check(self._h, self._lib.wtp_set_stream(self._h, C.c_void_p(int(stream_handle or 0)), int(ext)))
+
     # ---- measurement ---------------------------------------------------------------------------
     def timers(self):
         out = (C.c_double * 4)()
@@ -208,6 +214,25 @@ class RelaxSession:
         if sp.shape != (self.n,):
             raise L.WtpArgumentError("per-point spacing needs one value per snapshot point")
         L.check(self.ctx._h, self._lib.wtp_relax_set_spacing(self.ctx._h, _vp(sp)))
+
+    # ---- sharded sessions ------------------------------------------------------
+    def layers_dev(self, axis: int, lo_in: float, hi_in: float, lo_out: float, hi_out: float, d_lo_ptr: int,
+                   d_hi_ptr: int, cap: int):
+        """Boundary layers of the movable points into device buffers of `cap` packed 4-vectors each;
+        returns (n_lo, n_hi, n_stray_lo, n_stray_hi) — the true counts, also when they exceed cap."""
+        cnt = (C.c_int64 * 4)()
+        rc = self._lib.wtp_relax_layers_dev(self.ctx._h, int(axis), float(lo_in), float(hi_in), float(lo_out),
+                                            float(hi_out), C.c_void_p(d_lo_ptr), C.c_void_p(d_hi_ptr), int(cap), cnt)
+        L.check(self.ctx._h, rc)
+        return tuple(int(c) for c in cnt)
+
+    def set_fixed_dev(self, d_fixed4_ptr: int, n_fixed_new: int):
+        """Replace the fixed head of the snapshot by n_fixed_new packed 4-vectors in device memory."""
+        rc = self._lib.wtp_relax_set_fixed_dev(self.ctx._h, C.c_void_p(d_fixed4_ptr) if n_fixed_new else None,
+                                               int(n_fixed_new))
+        L.check(self.ctx._h, rc)
+        self.n += int(n_fixed_new) - self.n_fixed
+        self.n_fixed = int(n_fixed_new)
 
     def close(self):
         if self._open and self.ctx._h:

@@ -27,18 +27,71 @@ import torch
 
 
 class GpuEngine:
-    """Local sweep through libwtp on this rank's GPU (device-resident in and out)."""
+    """Local sweep through libwtp on this rank's GPU.  The session stays resident between
+    iterations: the owned points never leave the library's sorted state, only the boundary layers
+    (out) and the ghost layer (in) cross the C ABI (wtp_relax_layers_dev / wtp_relax_set_fixed_dev).
+    The library is put on torch's current stream, so RCCL results, torch ops and libwtp launches are
+    ordered without host synchronisation."""
 
-    def __init__(self, ctx, spacing, force, k, alpha_lo, alpha_max):
+    resident = True
+
+    def __init__(self, ctx, spacing, force, k, alpha_lo, alpha_max, device=None):
         self.ctx, self.spacing, self.force, self.k = ctx, spacing, force, k
         self.alpha_lo, self.alpha_max = alpha_lo, alpha_max
+        self.dev = torch.device("cuda", ctx.device) if device is None else torch.device(device)
+        ctx.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
+        self.sess = None
+        self.n_own = 0
+        self._lo = self._hi = None
+        self._cap = 0
 
+    def open(self, owned_xyz: torch.Tensor):
+        """(Re)start the session on a new owned set; the ghost layer starts empty."""
+        self.close()
+        owned_xyz = owned_xyz.contiguous()
+        self.n_own = int(owned_xyz.shape[0])
+        self.sess = self.ctx.relax(None, 0, self.spacing, self.force, self.k, self.alpha_lo, self.alpha_max,
+                                   device_ptr=(owned_xyz.data_ptr(), self.n_own, 3, np.float32))
+
+    def layers(self, axis, lo_in, hi_in, lo_out, hi_out):
+        """(lo rows, hi rows, strays): int32 (m, 4) views of packed {x, y, z, movable index}."""
+        if self._cap == 0:
+            self._grow(max(4096, self.n_own // 8))
+        while True:
+            n_lo, n_hi, s_lo, s_hi = self.sess.layers_dev(axis, lo_in, hi_in, lo_out, hi_out, self._lo.data_ptr(),
+                                                          self._hi.data_ptr(), self._cap)
+            if max(n_lo, n_hi) <= self._cap:
+                return self._lo[:n_lo], self._hi[:n_hi], s_lo + s_hi
+            self._grow(int(1.25 * max(n_lo, n_hi)) + 1024)
+
+    def _grow(self, cap):
+        self._cap = int(cap)
+        self._lo = torch.empty((self._cap, 4), dtype=torch.int32, device=self.dev)
+        self._hi = torch.empty((self._cap, 4), dtype=torch.int32, device=self.dev)
+
+    def set_ghosts(self, rows4: torch.Tensor):
+        rows4 = rows4.contiguous()
+        self.sess.set_fixed_dev(rows4.data_ptr(), int(rows4.shape[0]))
+
+    def step(self):
+        return self.sess.step(True)
+
+    def positions(self) -> torch.Tensor:
+        out = torch.empty((self.n_own, 3), dtype=torch.float32, device=self.dev)
+        if self.n_own:
+            self.sess.positions_dev(out.data_ptr())
+        return out
+
+    def close(self):
+        if self.sess is not None:
+            self.sess.close()
+            self.sess = None
+
+    # one-shot form (kept for engines without resident state, and for A/B timing)
     def sweep(self, local_xyz: torch.Tensor, n_ghost: int):
         n = local_xyz.shape[0]
         out = torch.empty((n - n_ghost, 3), dtype=local_xyz.dtype, device=local_xyz.device)
-        # libwtp works on its own HIP stream: everything torch queued to build `local_xyz` must have
-        # finished before the library reads it (the library synchronises its stream before returning)
-        torch.cuda.current_stream(local_xyz.device).synchronize()
+        self.close()
         sess = self.ctx.relax(None, n_ghost, self.spacing, self.force, self.k, self.alpha_lo, self.alpha_max,
                               device_ptr=(local_xyz.data_ptr(), n, 3, np.float32))
         try:
@@ -58,14 +111,16 @@ class ShardedRelax:
     """Owns this rank's points (positions + global ids) and runs sharded repel iterations."""
 
     def __init__(self, engine, dist, owned_xyz: torch.Tensor, owned_gid: torch.Tensor, cuts, ghost_width: float,
-                 rank: int = None, world: int = None, comm_device=None, margin: float = None):
+                 rank: int = None, world: int = None, comm_device=None, margin: float = None, legacy: bool = False):
         """comm_device: where collective payloads live — the points' own device for RCCL ("nccl"
         backend), "cpu" to stage through host memory when the backend is gloo (rehearsals with
         several ranks on one GPU)."""
         self.engine, self.dist = engine, dist
         self.rank = dist.get_rank() if rank is None else rank
         self.world = dist.get_world_size() if world is None else world
-        self.xyz, self.gid = owned_xyz, owned_gid
+        self.resident = bool(getattr(engine, "resident", False)) and not legacy
+        self._open = False
+        self._xyz, self.gid = owned_xyz, owned_gid
         self.dev = owned_xyz.device
         self.cdev = torch.device(comm_device) if comm_device is not None else self.dev
         self.cuts = torch.as_tensor(cuts, dtype=owned_xyz.dtype, device=self.dev).reshape(-1)
@@ -77,6 +132,17 @@ class ShardedRelax:
         self.migrations = 0
         self.last_local_points = int(owned_xyz.shape[0])
         self.history = []
+
+    @property
+    def xyz(self) -> torch.Tensor:
+        """Owned positions, in the order of self.gid (fetched from the engine when it holds them)."""
+        if self.resident and self._open:
+            return self.engine.positions()
+        return self._xyz
+
+    @xyz.setter
+    def xyz(self, v):
+        self._xyz = v
 
     # ---- point-to-point exchange with the two slab neighbours ------------------------------------
     def _exchange(self, to_lo: torch.Tensor, split_lo: int, to_hi: torch.Tensor, split_hi: int):
@@ -94,8 +160,8 @@ class ShardedRelax:
         m_from_lo, n_from_lo = (int(cnt[lo, 2]), int(cnt[lo, 3])) if lo >= 0 else (0, 0)
         m_from_hi, n_from_hi = (int(cnt[hi, 0]), int(cnt[hi, 1])) if hi < W else (0, 0)
         cols = to_lo.shape[1]
-        from_lo = torch.empty((n_from_lo, cols), dtype=to_lo.dtype, device=self.cdev)
-        from_hi = torch.empty((n_from_hi, cols), dtype=to_lo.dtype, device=self.cdev)
+        both = torch.empty((n_from_lo + n_from_hi, cols), dtype=to_lo.dtype, device=self.cdev)
+        from_lo, from_hi = both[:n_from_lo], both[n_from_lo:]
         ops = []
         if lo >= 0:
             if to_lo.shape[0]:
@@ -110,7 +176,9 @@ class ShardedRelax:
         if ops:
             for req in d.batch_isend_irecv(ops):
                 req.wait()
-        return from_lo.to(self.dev), m_from_lo, from_hi.to(self.dev), m_from_hi
+        both = both.to(self.dev)
+        self._last_recv = both  # [from_lo ; from_hi], contiguous
+        return both[:n_from_lo], m_from_lo, both[n_from_lo:], m_from_hi
 
     def _pack(self, mask):
         return self._pack_rows(self.xyz[mask], self.gid[mask])
@@ -131,8 +199,102 @@ class ShardedRelax:
         hi = float(self.cuts[self.rank]) if self.rank < self.world - 1 else math.inf
         return lo, hi
 
+    # ---- resident path: rows are 4 int32 words {x, y, z, w}; a migrant takes two rows ----------------
+    @staticmethod
+    def _rows4(xyz):
+        pad = torch.zeros((xyz.shape[0], 1), dtype=torch.int32, device=xyz.device)
+        return torch.cat([xyz.contiguous().view(torch.int32), pad], 1)
+
+    @staticmethod
+    def _pack_migrants(xyz, gid):
+        m = xyz.shape[0]
+        rows = torch.zeros((m, 8), dtype=torch.int32, device=xyz.device)
+        rows[:, :3] = xyz.contiguous().view(torch.int32)
+        rows[:, 3] = (gid & 0xFFFFFFFF).to(torch.int32)
+        rows[:, 4] = (gid >> 32).to(torch.int32)
+        return rows.view(2 * m, 4)
+
+    @staticmethod
+    def _unpack_migrants(rows, dtype):
+        r = rows.contiguous().view(-1, 8)
+        xyz = r[:, :3].contiguous().view(dtype)
+        gid = (r[:, 3].to(torch.int64) & 0xFFFFFFFF) | (r[:, 4].to(torch.int64) << 32)
+        return xyz, gid
+
+    def _step_resident(self):
+        eng = self.engine
+        lo, hi = self._bounds()
+        if not self._open:
+            eng.open(self._xyz)
+            self._open = True
+            self._xyz = None
+        n_ghost = 0
+        if self.world > 1:
+            w_eff = self.w + self.margin
+            # 1. boundary layers straight from the library's state; strays decide on migration
+            lo_rows, hi_rows, n_stray = eng.layers(2, lo + w_eff, hi - w_eff, lo - self.margin, hi + self.margin)
+            migrate = n_stray > 0
+            split_lo = split_hi = 0
+            emigrants = []
+            if migrate:
+                self.migrations += 1
+                xyz = eng.positions()
+                z = xyz[:, 2]
+                go_lo, go_hi = z < lo, z >= hi
+                keep = ~(go_lo | go_hi)
+                mig_lo = self._pack_migrants(xyz[go_lo], self.gid[go_lo])
+                mig_hi = self._pack_migrants(xyz[go_hi], self.gid[go_hi])
+                split_lo, split_hi = int(mig_lo.shape[0]), int(mig_hi.shape[0])
+                lo_rows = torch.cat([mig_lo, self._rows4(xyz[keep & (z < lo + w_eff)])])
+                hi_rows = torch.cat([mig_hi, self._rows4(xyz[keep & (z >= hi - w_eff)])])
+                emigrants = [self._rows4(xyz[go_lo]), self._rows4(xyz[go_hi])]
+            from_lo, m_lo, from_hi, m_hi = self._exchange(lo_rows, split_lo, hi_rows, split_hi)
+            # 2. membership changed (someone left or arrived): restart the session on the new owned set
+            if migrate or m_lo or m_hi:
+                if not migrate:
+                    xyz = eng.positions()
+                    parts_x, parts_g = [xyz], [self.gid]
+                else:
+                    parts_x, parts_g = [xyz[keep]], [self.gid[keep]]
+                for buf, m in ((from_lo, m_lo), (from_hi, m_hi)):
+                    if m:
+                        x, g = self._unpack_migrants(buf[:m], xyz.dtype)
+                        parts_x.append(x)
+                        parts_g.append(g)
+                self.gid = torch.cat(parts_g)
+                eng.open(torch.cat(parts_x))
+                ghosts = torch.cat([from_lo[m_lo:], from_hi[m_hi:]] + emigrants)
+            else:
+                ghosts = self._last_recv
+            # 3. ghosts = the neighbours' layers (+ my own emigrants, cut from their new owner's layer
+            #    before they arrived) become the fixed head of the local snapshot
+            n_ghost = int(ghosts.shape[0])
+            eng.set_ghosts(ghosts)
+        n_own = int(self.gid.shape[0])
+        self.last_local_points = n_own + n_ghost
+        st = eng.step()
+        return self._reduce(st, n_ghost, n_own)
+
+    def _reduce(self, st, n_ghost, n_own):
+        """Global stop-rule scalars (src/repel.jl:293,374-386): one all-gather of four doubles."""
+        mine = torch.tensor([st["max_force"], st["sum_u"], st["sum_u2"], float(st["n_move"])], dtype=torch.float64,
+                            device=self.cdev)
+        if self.world > 1:
+            allv = [torch.zeros_like(mine) for _ in range(self.world)]
+            self.dist.all_gather(allv, mine)
+            allv = torch.stack(allv).cpu()
+        else:
+            allv = mine.reshape(1, 4).cpu()
+        out = dict(max_force=float(allv[:, 0].max()), sum_u=float(allv[:, 1].sum()), sum_u2=float(allv[:, 2].sum()),
+                   n_move=int(allv[:, 3].sum()), n_ghost=n_ghost, n_owned=n_own,
+                   n_fallback=int(st.get("n_fallback", 0)))
+        self.history.append(out)
+        return out
+
     # ---- one iteration ---------------------------------------------------------------------------------
     def step(self):
+        if self.resident:
+            return self._step_resident()
         lo, hi = self._bounds()
         if self.world > 1:
             z = self.xyz[:, 2]
@@ -177,16 +339,8 @@ class ShardedRelax:
         self.last_local_points = int(local.shape[0])
         new_xyz, st = self.engine.sweep(local, n_ghost)
         self.xyz = new_xyz
-        # 4. global reductions of the stop-rule scalars (src/repel.jl:293,374-386)
-        red = torch.tensor([st["sum_u"], st["sum_u2"], float(st["n_move"])], dtype=torch.float64, device=self.cdev)
-        mx = torch.tensor([st["max_force"]], dtype=torch.float64, device=self.cdev)
-        if self.world > 1:
-            self.dist.all_reduce(red, op=self.dist.ReduceOp.SUM)
-            self.dist.all_reduce(mx, op=self.dist.ReduceOp.MAX)
-        out = dict(max_force=float(mx[0]), sum_u=float(red[0]), sum_u2=float(red[1]), n_move=int(red[2]),
-                   n_ghost=n_ghost, n_owned=int(self.xyz.shape[0]), n_fallback=int(st.get("n_fallback", 0)))
-        self.history.append(out)
-        return out
+        # 4. global reductions of the stop-rule scalars
+        return self._reduce(st, n_ghost, int(new_xyz.shape[0]))
 
     def run(self, iters: int):
         last = None
