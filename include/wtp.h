@@ -83,6 +83,8 @@ typedef struct wtp_step_stats {
     int64_t argmin_j;  /*   movable point with the smallest nn_dist, and its neighbour;  */
     double argmin_r;   /*   -1/-1/inf when n_move == 0                                    */
     int64_t n_fallback;/* queries that left the 27-cell fast path (diagnostic)           */
+    int64_t n_uncovered;/* sharded sessions: queries whose neighbourhood reaches past the
+                          covered range (wtp_relax_set_coverage); 0 when unlimited        */
 } wtp_step_stats;
 
 /* ---- lifetime ------------------------------------------------------------------ */
@@ -189,6 +191,14 @@ int wtp_set_stream(wtp_ctx* ctx, void* hip_stream, int external);
  * points are written per layer; counts report the true sizes.  */
 int wtp_relax_layers_dev(wtp_ctx* ctx, int axis, double lo_in, double hi_in, double lo_out, double hi_out,
                          void* d_lo4, void* d_hi4, int64_t cap, int64_t counts[4]);
+
+/* Coverage of a sharded session: the caller guarantees that the snapshot holds every point of
+ * the global cloud with lo <= coord[axis] <= hi (its slab plus the ghost layers; an end may be
+ * +-inf).  A sweep then counts in stats.n_uncovered the movable points whose answer needs more:
+ * a k-th neighbour (compact-support sweep: the law's support u0*s, or the nearest neighbour)
+ * farther away than the nearer end of that range — so the caller can widen the layer and redo
+ * the step (wtp_relax_revert).  axis < 0: unlimited (default).  */
+int wtp_relax_set_coverage(wtp_ctx* ctx, int axis, double lo, double hi);
 
 /* Replace the fixed head of the snapshot by n_fixed_new points (packed 4-vectors in device
  * memory, 4th component ignored).  Movable indices are unchanged; the next wtp_relax_step

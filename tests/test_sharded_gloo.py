@@ -95,16 +95,21 @@ def test_sharded_matches_single_domain(O, wtp, world, margin, resident):
     # margin=0: every crossing is handed over at once, so the migration path runs every iteration
     n_total, iters = 6000, 4
     ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
+    q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, iters, q, margin, resident))
              for r in range(world)]
     for p in procs:
         p.start()
-    conv, allp, n_ghost, n_move, migrations = q.get()
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+    try:
+        conv, allp, n_ghost, n_move, migrations = q.get(timeout=240)
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:  # a rank that died leaves its peers waiting in a collective
+            if p.is_alive():
+                p.terminate()
     x = wtp.synth.uniform(n_total, 3, np.float32, 7)
     s = float(n_total) ** (-1.0 / 3.0)
     ref = O.relax_loop(x, 0, s, 2, 0.2, 1.0, 3.0, 21, s / 2000, s / 20, max_iters=iters, tol=0.0, rebuild_every=1,
@@ -118,7 +123,7 @@ def test_sharded_matches_single_domain(O, wtp, world, margin, resident):
 
 # ---- the same logic with the PRODUCT engine: 2 ranks sharing the one GPU of the test box, payloads
 # staged through host memory because gloo carries CPU tensors (RCCL needs one GPU per rank) ----------
-def _gpu_worker(rank, world, port, n_total, iters, q):
+def _gpu_worker(rank, world, port, n_total, iters, q, ghost_w_over_s=None):
     for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -139,29 +144,41 @@ def _gpu_worker(rank, world, port, n_total, iters, q):
 
     xyz, gid, cuts = sharded.uniform_shard(gen, rank, world, n_total, 7, "cuda", chunk=50000)
     eng = sharded.GpuEngine(ctx, s, dict(kind=2, beta=0.2, u0=1.0, gamma=3.0), k, s / 2000, s / 20)
-    drv = sharded.ShardedRelax(eng, dist, xyz, gid, cuts, sharded.ghost_width(n_total, k), comm_device="cpu")
+    w = sharded.ghost_width(n_total, k) if ghost_w_over_s is None else ghost_w_over_s * s
+    drv = sharded.ShardedRelax(eng, dist, xyz, gid, cuts, w, comm_device="cpu")
     conv = [drv.step()["max_force"] for _ in range(iters)]
     allp = drv.gather_global(n_total)
     if rank == 0:
-        q.put((conv, allp.numpy()))
+        q.put((conv, allp.numpy(), drv.widened, drv.w / s))
     dist.barrier()
+    eng.close()
     ctx.close()
     dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-def test_sharded_gpu_engine_two_ranks_one_gpu(O, wtp):
+@pytest.mark.parametrize("ghost_w_over_s", [None, 0.6])
+def test_sharded_gpu_engine_two_ranks_one_gpu(O, wtp, ghost_w_over_s):
+    # ghost_w_over_s = 0.6: a ghost layer thinner than the force law's support — the sweep must
+    # notice (n_uncovered), and the driver must undo, widen and repeat until the answer is global
     n_total, iters, world = 120000, 3, 2
     ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
+    q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, n_total, iters, q)) for r in range(world)]
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, n_total, iters, q, ghost_w_over_s))
+             for r in range(world)]
     for p in procs:
         p.start()
-    conv, allp = q.get()
-    for p in procs:
-        p.join(300)
-        assert p.exitcode == 0
+    try:
+        conv, allp, widened, w_over_s = q.get(timeout=240)
+        for p in procs:
+            p.join(300)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    assert (widened == 0) if ghost_w_over_s is None else (widened >= 2 and w_over_s > 1.0)
     x = wtp.synth.uniform(n_total, 3, np.float32, 7)
     s = float(n_total) ** (-1.0 / 3.0)
     ref = O.relax_loop(x, 0, s, 2, 0.2, 1.0, 3.0, 21, s / 2000, s / 20, max_iters=iters, tol=0.0, rebuild_every=1,

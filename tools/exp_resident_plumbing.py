@@ -24,10 +24,12 @@ x = torch.empty((n, 3), dtype=torch.float32, device="cuda")
 ctx.gen_uniform_dev(7, 0, n, 3, np.float32, x.data_ptr())
 x[:, 2] /= world
 L = 1.0 / world
-w = sharded.ghost_width(n_total, k)
+gc = float(sys.argv[3]) if len(sys.argv) > 3 else 1.25
+w = sharded.ghost_width(n_total, k, ghost_cells=gc)
 margin = 0.25 * w
 w_eff = w + margin
 eng = sharded.GpuEngine(ctx, s, force, k, s / 2000, s / 20)
+eng.set_coverage(2, -w_eff, L + w_eff)
 eng.open(x)
 shift = torch.tensor([0, 0, L, 0], dtype=torch.float32, device="cuda")
 
@@ -47,8 +49,11 @@ def iteration(sync_each=False, T=None):
     return st, g.shape[0]
 
 
+unc = []
 for _ in range(3):
     st, ng = iteration()
+    unc.append(st['n_uncovered'])
+print('ghost_cells', gc, 'w/s', w / s, 'n_uncovered in the first iterations', unc, flush=True)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(iters):

@@ -38,7 +38,7 @@ class StepStats(C.Structure):
     _fields_ = [
         ("max_force", C.c_double), ("sum_u", C.c_double), ("sum_u2", C.c_double),
         ("n_move", C.c_int64), ("argmin_i", C.c_int64), ("argmin_j", C.c_int64),
-        ("argmin_r", C.c_double), ("n_fallback", C.c_int64),
+        ("argmin_r", C.c_double), ("n_fallback", C.c_int64), ("n_uncovered", C.c_int64),
     ]
 
 
@@ -67,6 +67,7 @@ SIGNATURES = {
     "wtp_set_stream": (_i, [_vp, _vp, _i]),
     "wtp_relax_layers_dev": (_i, [_vp, _i, _d, _d, _d, _d, _vp, _vp, _i64, C.POINTER(_i64)]),
     "wtp_relax_set_fixed_dev": (_i, [_vp, _vp, _i64]),
+    "wtp_relax_set_coverage": (_i, [_vp, _i, _d, _d]),
     "wtp_timers_get": (_i, [_vp, C.POINTER(_d)]),
     "wtp_timers_reset": (_i, [_vp]),
     "wtp_gen_uniform_dev": (_i, [_vp, C.c_uint64, _i64, _i64, _i, _i, _vp]),

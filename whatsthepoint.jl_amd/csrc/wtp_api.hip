@@ -542,9 +542,14 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
     if ((rc = ensure(ctx, ctx->diag, 128))) return rc;
     a.diag = (unsigned long long*)ctx->diag.p;
     a.brick_hcap = r.cs_sweep ? r.brick_hcap : 0;
+    a.cover_axis = r.cover_axis;
+    a.cover_lo = (T)r.cover_lo;
+    a.cover_hi = (T)r.cover_hi;
+    a.uncovered = (int32_t*)ctx->fb_count.p + 8; // second word group of the 64-byte counter block
+    WTP_HIP(ctx, hipMemsetAsync(a.uncovered, 0, sizeof(int32_t), ctx->stream));
     if ((rc = launch_sweep<T>(ctx, a, fresh))) return rc;
     int sp = span_begin(ctx, 2);
-    rc = launch_reduce_partials(ctx, a.partials, a.n_partials, a.fb_count, d_slot);
+    rc = launch_reduce_partials(ctx, a.partials, a.n_partials, a.fb_count, a.uncovered, d_slot);
     span_end(ctx, sp);
     if (rc) return rc;
     r.bufOld = r.bufP; // p_old (src/repel.jl:244)
@@ -809,6 +814,18 @@ WTP_API int wtp_relax_set_fixed_dev(wtp_ctx* ctx, const void* d_fixed4, int64_t 
     r.have_point_data = false;
     // the caller's array must outlive the copy: on a lent stream that is stream order, else wait
     return ctx->stream == ctx->own_stream ? sync(ctx) : WTP_OK;
+}
+
+WTP_API int wtp_relax_set_coverage(wtp_ctx* ctx, int axis, double lo, double hi) {
+    if (!ctx) return WTP_ERR_ARG;
+    RelaxState& r = ctx->relax;
+    if (!r.active) return fail(ctx, WTP_ERR_STATE, "wtp_relax_set_coverage before wtp_relax_init");
+    if (axis >= r.dim) return fail(ctx, WTP_ERR_ARG, "axis must be < dim (negative: unlimited)");
+    if (axis >= 0 && !(lo <= hi)) return fail(ctx, WTP_ERR_ARG, "need lo <= hi");
+    r.cover_axis = axis < 0 ? -1 : axis;
+    r.cover_lo = lo;
+    r.cover_hi = hi;
+    return WTP_OK;
 }
 
 WTP_API int wtp_timers_get(wtp_ctx* ctx, double out[4]) {

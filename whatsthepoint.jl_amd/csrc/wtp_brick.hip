@@ -578,6 +578,10 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
                     o.w = qp.w;
                     const bool has = nid != 0x7FFFFFFF;
                     const float nd = has ? wsqrt(nd2) : Lim<float>::inf();
+                    // sharded sessions: the k-set (CS: the support and the nearest neighbour) must lie
+                    // inside the range the ghost layer covers, else the local answer is not the global one
+                    const float need = CS ? (nd2 > spec.lim ? nd2 : spec.lim) : cut;
+                    if (reaches_past_cover<float>(a, qp.x, qp.y, qp.z, need)) atomicAdd(a.uncovered, 1);
                     a.out[gslot] = o;
                     a.forces[gslot] = f;
                     a.nn_dist[gslot] = nd;

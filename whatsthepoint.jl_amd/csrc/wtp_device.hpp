@@ -160,6 +160,17 @@ __device__ inline T step_point(const SearchArgs<T>& a, T s, T xi, T yi, T zi, T 
 }
 
 // ---- per-thread partial and block reduction -------------------------------------------------
+// Sharded sessions: does a neighbourhood of squared radius need2 around the query stay inside the
+// coordinate range the snapshot is complete for?  (range ends may be +-inf)
+template <typename T>
+__device__ inline bool reaches_past_cover(const SearchArgs<T>& a, T qx, T qy, T qz, T need2) {
+    if (a.cover_axis < 0) return false;
+    const T v = a.cover_axis == 0 ? qx : (a.cover_axis == 1 ? qy : qz);
+    const T dl = v - a.cover_lo, dh = a.cover_hi - v;
+    const T d = dl < dh ? dl : dh;
+    return !(d > (T)0 && need2 <= d * d);
+}
+
 struct Acc { // plain aggregate: lives in LDS too
     double max_force;
     double sum_u;

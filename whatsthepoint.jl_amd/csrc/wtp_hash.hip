@@ -524,7 +524,8 @@ int launch_gen_uniform(wtp_ctx* ctx, uint64_t seed, int64_t first, int64_t n, in
 
 // ---- final reduction of per-block partials (fixed order => deterministic) --------------------
 __global__ void reduce_partials_kernel(const Partial* __restrict__ parts, int n_parts,
-                                       const int32_t* __restrict__ fb_count, wtp_step_stats* __restrict__ out) {
+                                       const int32_t* __restrict__ fb_count,
+                                       const int32_t* __restrict__ uncovered, wtp_step_stats* __restrict__ out) {
     __shared__ Acc sm[kThreads / 64];
     Acc acc = acc_empty();
     for (int i = threadIdx.x; i < n_parts; i += blockDim.x) {
@@ -549,13 +550,14 @@ __global__ void reduce_partials_kernel(const Partial* __restrict__ parts, int n_
         out->argmin_j = acc.argmin_j;
         out->argmin_r = acc.argmin_r;
         out->n_fallback = fb_count ? *fb_count : 0;
+        out->n_uncovered = uncovered ? *uncovered : 0;
     }
 }
 
 int launch_reduce_partials(wtp_ctx* ctx, const Partial* parts, int n_parts, const int32_t* fb_count,
-                           wtp_step_stats* d_slot) {
+                           const int32_t* uncovered, wtp_step_stats* d_slot) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, parts, n_parts,
-                       fb_count, d_slot);
+                       fb_count, uncovered, d_slot);
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;
 }

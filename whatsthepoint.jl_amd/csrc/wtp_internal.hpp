@@ -108,6 +108,11 @@ template <typename T> struct SearchArgs {
     int32_t* fb_count;
     int32_t* fb2_list;         // second level: wave kernel -> serial kernel
     int32_t* fb2_count;
+    // sharded sessions: the snapshot is complete only for cover_lo <= coord[cover_axis] <= cover_hi;
+    // queries whose neighbourhood reaches past that range are counted (wtp_relax_set_coverage)
+    int32_t cover_axis;        // -1: unlimited
+    T cover_lo, cover_hi;
+    int32_t* uncovered;
     // tunables
     T gamma_cap;               // initial filter radius cap, in cell edges
     int32_t brick_hcap;        // LDS point capacity for the brick kernel (0 = default)
@@ -135,6 +140,8 @@ struct RelaxState {
     double spacing_max = 0;  // largest spacing value (host-side max of the per-point array)
     int brick_hcap = 0;      // LDS point capacity of the sweep's brick kernel (0 = not chosen yet)
     bool cs_sweep = false;   // compact-support sweep in use (ClippedSpacingForce)
+    int cover_axis = -1;     // sharded session: snapshot complete for cover_lo <= coord[axis] <= cover_hi
+    double cover_lo = 0, cover_hi = 0;
 };
 
 } // namespace wtp
@@ -224,7 +231,7 @@ template <typename T>
 int launch_radius_fill(wtp_ctx* ctx, SearchArgs<T>& a, T r, const int64_t* d_offsets,
                        int32_t* d_idx);
 int launch_reduce_partials(wtp_ctx* ctx, const Partial* parts, int n_parts, const int32_t* fb_count,
-                           wtp_step_stats* d_stats_slot);
+                           const int32_t* uncovered, wtp_step_stats* d_stats_slot);
 template <typename T>
 int launch_unpermute(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int64_t n_fixed, int dim, T* d_xyz_out);
 template <typename T>

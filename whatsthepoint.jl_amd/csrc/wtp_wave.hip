@@ -263,6 +263,7 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
                 a.nn_dist[slot] = nd;
                 a.nn_id[slot] = nid;
                 acc_point(acc, (double)f, (double)nd, (double)s, id, nid);
+                if (reaches_past_cover<T>(a, q.x, q.y, q.z, sm->od2[K - 1])) atomicAdd(a.uncovered, 1);
             }
         }
         __builtin_amdgcn_wave_barrier();

@@ -126,7 +126,7 @@ class Context:
 
 def _stats_dict(s: L.StepStats):
     return dict(max_force=s.max_force, sum_u=s.sum_u, sum_u2=s.sum_u2, n_move=s.n_move, argmin_i=s.argmin_i,
-                argmin_j=s.argmin_j, argmin_r=s.argmin_r, n_fallback=s.n_fallback)
+                argmin_j=s.argmin_j, argmin_r=s.argmin_r, n_fallback=s.n_fallback, n_uncovered=s.n_uncovered)
 
 
 class RelaxSession:
@@ -233,6 +233,11 @@ class RelaxSession:
         L.check(self.ctx._h, rc)
         self.n += int(n_fixed_new) - self.n_fixed
         self.n_fixed = int(n_fixed_new)
+
+    def set_coverage(self, axis: int, lo: float = 0.0, hi: float = 0.0):
+        """The snapshot is complete for lo <= coord[axis] <= hi (slab + ghost layers); sweeps report
+        in n_uncovered the points whose neighbourhood reaches past it.  axis < 0: unlimited."""
+        L.check(self.ctx._h, self._lib.wtp_relax_set_coverage(self.ctx._h, int(axis), float(lo), float(hi)))
 
     def close(self):
         if self._open and self.ctx._h:

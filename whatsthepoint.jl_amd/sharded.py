@@ -42,6 +42,7 @@ class GpuEngine:
         ctx.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
         self.sess = None
         self.n_own = 0
+        self.coverage = None  # (axis, lo, hi): coordinate range the local snapshot is complete for
         self._lo = self._hi = None
         self._cap = 0
 
@@ -52,6 +53,16 @@ class GpuEngine:
         self.n_own = int(owned_xyz.shape[0])
         self.sess = self.ctx.relax(None, 0, self.spacing, self.force, self.k, self.alpha_lo, self.alpha_max,
                                    device_ptr=(owned_xyz.data_ptr(), self.n_own, 3, np.float32))
+        if self.coverage:
+            self.sess.set_coverage(*self.coverage)
+
+    def set_coverage(self, axis: int, lo: float, hi: float):
+        self.coverage = (int(axis), float(lo), float(hi))
+        if self.sess is not None:
+            self.sess.set_coverage(*self.coverage)
+
+    def revert(self):
+        self.sess.revert()
 
     def layers(self, axis, lo_in, hi_in, lo_out, hi_out):
         """(lo rows, hi rows, strays): int32 (m, 4) views of packed {x, y, z, movable index}."""
@@ -130,6 +141,7 @@ class ShardedRelax:
         # widened by the same margin so that strays still see (and are seen by) their neighbours
         self.margin = 0.25 * self.w if margin is None else float(margin)
         self.migrations = 0
+        self.widened = 0  # times the ghost layer had to grow because a sweep reported uncovered queries
         self.last_local_points = int(owned_xyz.shape[0])
         self.history = []
 
@@ -221,10 +233,25 @@ class ShardedRelax:
         gid = (r[:, 3].to(torch.int64) & 0xFFFFFFFF) | (r[:, 4].to(torch.int64) << 32)
         return xyz, gid
 
-    def _step_resident(self):
+    def _set_coverage(self):
+        """Tell the engine which z-range its snapshot is complete for: the slab plus what the
+        neighbours' layers cover (they send everything within w + margin of the cut)."""
+        if self.cuts.numel() > 1:
+            thick = float((self.cuts[1:] - self.cuts[:-1]).min())
+            # the range a neighbour's layer covers (w + margin past the cut) must belong to that
+            # neighbour alone, strays of the rank behind it (up to margin) included
+            if thick < self.w + 2.0 * self.margin:
+                raise ValueError(f"slabs of thickness {thick:g} are thinner than a ghost layer "
+                                 f"(w={self.w:g}): use fewer ranks for this cloud")
+        if hasattr(self.engine, "set_coverage"):
+            lo, hi = self._bounds()
+            self.engine.set_coverage(2, lo - (self.w + self.margin), hi + (self.w + self.margin))
+
+    def _step_resident(self, attempt: int = 0):
         eng = self.engine
         lo, hi = self._bounds()
         if not self._open:
+            self._set_coverage()
             eng.open(self._xyz)
             self._open = True
             self._xyz = None
@@ -273,20 +300,32 @@ class ShardedRelax:
         n_own = int(self.gid.shape[0])
         self.last_local_points = n_own + n_ghost
         st = eng.step()
-        return self._reduce(st, n_ghost, n_own)
+        out = self._reduce(st, n_ghost, n_own)
+        if out["n_uncovered"] > 0:
+            # some rank's sweep needed points beyond its ghost layer (a k-th neighbour past the cover):
+            # every rank sees the same global count, so all undo the step, widen and redo it
+            if attempt >= 4 or not hasattr(eng, "revert"):
+                raise RuntimeError(f"{out['n_uncovered']} queries reach past the ghost layer (w={self.w:g})")
+            eng.revert()
+            self.history.pop()
+            self.w *= 1.5
+            self.widened += 1
+            self._set_coverage()
+            return self._step_resident(attempt + 1)
+        return out
 
     def _reduce(self, st, n_ghost, n_own):
-        """Global stop-rule scalars (src/repel.jl:293,374-386): one all-gather of four doubles."""
-        mine = torch.tensor([st["max_force"], st["sum_u"], st["sum_u2"], float(st["n_move"])], dtype=torch.float64,
-                            device=self.cdev)
+        """Global stop-rule scalars (src/repel.jl:293,374-386) and the coverage count: one all-gather."""
+        mine = torch.tensor([st["max_force"], st["sum_u"], st["sum_u2"], float(st["n_move"]),
+                             float(st.get("n_uncovered", 0))], dtype=torch.float64, device=self.cdev)
         if self.world > 1:
             allv = [torch.zeros_like(mine) for _ in range(self.world)]
             self.dist.all_gather(allv, mine)
             allv = torch.stack(allv).cpu()
         else:
-            allv = mine.reshape(1, 4).cpu()
+            allv = mine.reshape(1, 5).cpu()
         out = dict(max_force=float(allv[:, 0].max()), sum_u=float(allv[:, 1].sum()), sum_u2=float(allv[:, 2].sum()),
-                   n_move=int(allv[:, 3].sum()), n_ghost=n_ghost, n_owned=n_own,
+                   n_move=int(allv[:, 3].sum()), n_uncovered=int(allv[:, 4].sum()), n_ghost=n_ghost, n_owned=n_own,
                    n_fallback=int(st.get("n_fallback", 0)))
         self.history.append(out)
         return out
@@ -398,12 +437,13 @@ def uniform_shard(ctx_gen, rank: int, world: int, n_total: int, seed: int, devic
     return xyz[order].contiguous(), gid[order].contiguous(), cuts
 
 
-def ghost_width(n_total: int, k: int, rho: float = 8.0, ghost_cells: float = 2.0, dim: int = 3) -> float:
-    """ghost_cells x the hash cell edge libwtp will choose for this density (csrc/wtp_hash.hip
+def ghost_width(n_total: int, k: int, rho: float = 8.0, ghost_cells: float = 1.25, dim: int = 3) -> float:
+    """Initial ghost width: ghost_cells x the k-NN hash cell edge for this density (csrc/wtp_hash.hip
     build_hash: c = (rho_k / density)^(1/dim), rho_k = 0.381 k rho/8; c ~ 1.17 r_k).
     Correctness needs every owned query's k nearest points to be present locally, i.e.
-    w >= max r_k.  2 cells = 2.3x the mean r_k: a ball of that radius holds ~270 points at the
-    benchmark density, so a k=21 query cannot reach past it.  (A local certificate clamped to the
-    ghost extent, for strongly graded clouds, is future work: DESIGN.md §7.)"""
+    w >= max r_k.  That is not assumed but checked: the sweep counts the queries whose k-th
+    neighbour lies farther than w (wtp_relax_set_coverage -> stats.n_uncovered) and the driver
+    undoes the step, widens the layer by 1.5x and repeats it.  1.25 cells = 1.46x the mean r_k
+    (a ball holding ~65 points at uniform density) rarely needs that."""
     rho_k = (0.381 if dim == 3 else 0.436) * k * (rho / 8.0)
     return ghost_cells * (max(rho_k, 1.0) / n_total) ** (1.0 / dim)
