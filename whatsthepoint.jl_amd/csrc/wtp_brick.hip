@@ -403,6 +403,10 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
                 cs_fail = !(spec.lim <= tau);
                 tau = tcs < tau ? tcs : tau;
             }
+            // CS scan filter: d2 with fused multiply-adds (3 VALU instead of 5) against a threshold
+            // 4 ulp wider.  The ring pass below recomputes the canonical d2 of every survivor and
+            // applies the exact cut, so the filter only has to be conservative.
+            float tau_s = CS ? tau * (1.f + 0x1p-21f) : tau;
 
             // ---- scan / select loop: one instance of the network serves prunes and the final cut
             // LDS byte addresses: points at [0, hcap*16), this lane's ring row j at ring_b + j*512
@@ -436,10 +440,16 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
                         lds_read_group(c, lds_base + pa);
 #pragma unroll
                         for (int u = 0; u < SU; ++u) {
-                            const float d = dist2<float>(qp.x, qp.y, qp.z, c[u].x, c[u].y, c[u].z);
+                            float d;
+                            if (CS) {
+                                const float ex = qp.x - c[u].x, ey = qp.y - c[u].y, ez = qp.z - c[u].z;
+                                d = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
+                            } else {
+                                d = dist2<float>(qp.x, qp.y, qp.z, c[u].x, c[u].y, c[u].z);
+                            }
                             // run-end masking folded into the threshold (a VALU select) instead of
                             // and-ing lane masks on the scalar unit: no VALU->SALU->VALU round trip
-                            const float tl = (pa + 16u * u < ea) ? tau : -1.f;
+                            const float tl = (pa + 16u * u < ea) ? (CS ? tau_s : tau) : -1.f;
                             bool take = d <= tl;
                             if (MODE == 0) take = take && (w_to_id(c[u].w) != skip_id);
                             *reinterpret_cast<uint16_t*>(smem_raw + (take ? ra : dump_b)) = (uint16_t)(pa + 16u * u);
@@ -463,6 +473,7 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
                             giveup = true;
                             ra = ring_b;
                             tau = -1.f;
+                            tau_s = -1.f;
                         }
                         continue; // resume the row scan
                     }
