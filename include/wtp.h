@@ -171,6 +171,25 @@ int wtp_relax_set_spacing(wtp_ctx* ctx, const void* spacing);
 /* Release the relax state (device buffers stay pooled in the context). */
 int wtp_relax_end(wtp_ctx* ctx);
 
+/* ---- isinside: the post-filter of the volume-only repel (src/repel.jl:90) -----------------
+ * 3-D, replaces isinside(testpoint, cloud|boundary) + _greens (src/isinside.jl:86-106) for a whole
+ * array of test points: g_i = sum_j ((area_j (x_i - p_j)) . n_j) / |x_i - p_j|^3 over the m boundary
+ * elements (centroid p, unit normal n, area), inside_out[i] = (g_i < -2 pi); a test point that
+ * coincides with an element gives NaN and is reported outside, as in the reference.  Host arrays:
+ * test_xyz n x 3, elem_xyz / elem_normal m x 3, elem_area m, all of dtype; g_out n values or NULL.
+ * g is evaluated with fused multiply-adds and a 1-ulp rsqrt: it agrees with a term-by-term
+ * evaluation to ~1e-6 relative, so only points with |g + 2 pi| below that can flip.  */
+int wtp_isinside_greens(wtp_ctx* ctx, const void* test_xyz, int64_t n, const void* elem_xyz,
+                        const void* elem_normal, const void* elem_area, int64_t m, int dtype,
+                        uint8_t* inside_out, void* g_out);
+/* 2-D, replaces isinside(testpoint, pts) (src/isinside.jl:17-33): winding sum of the signed angles
+ * around the ordered, closed polygon poly_xy (m x 2); inside iff |sum| >= 1e3 eps(dtype), or the
+ * point coincides (r < 100 eps) with a polygon point.  The ordering check of
+ * _validate_polygon_ordering (:36-69) is the caller's (it needs the polygon only).  m < 3 is an
+ * argument error.  sum_out: n values or NULL.  */
+int wtp_isinside_winding(wtp_ctx* ctx, const void* test_xy, int64_t n, const void* poly_xy, int64_t m,
+                         int dtype, uint8_t* inside_out, void* sum_out);
+
 /* ---- sharded sessions (no counterpart in the reference) --------------
  * One rank sweeps one spatial slab.  Its session's fixed head is the ghost layer received
  * from the neighbouring ranks, its movable tail the points it owns.  The two calls below

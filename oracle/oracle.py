@@ -237,3 +237,28 @@ def spacing_boundary_layer(xyz, bnd, at_wall, bulk, layer_thickness):
         ct(at_wall), ct(bulk), ct(layer_thickness), _p(out),
     )
     return out
+
+
+def isinside_greens(test, pts, normals, areas):
+    """3-D isinside (src/isinside.jl:86-106): returns (inside bool[n], g[n])."""
+    test = _xyz(test)
+    dt = test.dtype
+    pts, normals = _xyz(pts).astype(dt), _xyz(normals).astype(dt)
+    areas = np.ascontiguousarray(areas, dtype=dt)
+    g = np.empty(len(test), dtype=dt)
+    inside = np.empty(len(test), dtype=np.uint8)
+    getattr(lib(), f"wtpo_isinside_greens_{_suf(dt)}")(
+        _p(test), C.c_int64(len(test)), _p(pts), _p(normals), _p(areas), C.c_int64(len(pts)), _p(g), _p(inside))
+    return inside.astype(bool), g
+
+
+def isinside_winding(test, poly):
+    """2-D isinside (src/isinside.jl:17-33): returns (inside bool[n], angle sums[n])."""
+    test = _xyz(test)
+    dt = test.dtype
+    poly = _xyz(poly).astype(dt)
+    sums = np.empty(len(test), dtype=dt)
+    inside = np.empty(len(test), dtype=np.uint8)
+    getattr(lib(), f"wtpo_isinside_winding_{_suf(dt)}")(
+        _p(test), C.c_int64(len(test)), _p(poly), C.c_int64(len(poly)), _p(sums), _p(inside))
+    return inside.astype(bool), sums

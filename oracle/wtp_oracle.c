@@ -10,6 +10,7 @@
  *   src/repel.jl:202-339     _relax! loop, :350-403 helpers, :565-580 cull mask
  *   src/repel_forces.jl:37,57-60,96-100,124-127   the four force laws
  *   src/discretization/spacings.jl:19-23,67-72,121-133   variable spacings
+ *   src/isinside.jl:17-33,86-106   the isinside post-filter of repel (src/repel.jl:90)
  * Third-party arithmetic it stands in for (source NOT in the reference tree, versions only
  * compat-bounded in Project.toml:39-45): NearestNeighbors.jl 0.4.8+ (KDTree, knn, knn!,
  * inrange), Meshes.jl 0.56/0.57 (KNearestSearch, BallSearch), Distances.jl 0.10
@@ -19,7 +20,8 @@
  * PARITY STATUS.  The reference cannot run here (no Julia toolchain in the image; nothing
  * was refused).  Pinned against the reference's own tests: the closed-form known answers
  * of test/neighbors.jl:34-57, test/topology.jl:43-66, test/metrics.jl:115-143,
- * test/repel.jl:117-183 (force laws), :301-325 (cull masks) — see tests/test_oracle_kat.py.
+ * test/repel.jl:117-183 (force laws), :301-325 (cull masks), test/isinside.jl:1-75 (unit
+ * squares; box.stl inside/outside points) — see tests/test_oracle_kat.py.
  * NOT pinned by anything the reference holds: the order of equidistant neighbours, which
  * equidistant point takes slot k, and repelled coordinates ("parity unpinned" for those;
  * SURVEY.md §8c).  The canonical rule defined here is ascending (d2, index).
@@ -35,6 +37,8 @@
 #define SQRT sqrtf
 #define POW powf
 #define EXP expf
+#define ATAN2 atan2f
+#define REAL_EPS FLT_EPSILON
 #define REAL_MAX FLT_MAX
 #include "wtp_oracle_impl.h"
 #undef REAL
@@ -42,6 +46,8 @@
 #undef SQRT
 #undef POW
 #undef EXP
+#undef ATAN2
+#undef REAL_EPS
 #undef REAL_MAX
 
 #define REAL double
@@ -49,6 +55,8 @@
 #define SQRT sqrt
 #define POW pow
 #define EXP exp
+#define ATAN2 atan2
+#define REAL_EPS DBL_EPSILON
 #define REAL_MAX DBL_MAX
 #include "wtp_oracle_impl.h"
 #undef REAL
@@ -56,6 +64,8 @@
 #undef SQRT
 #undef POW
 #undef EXP
+#undef ATAN2
+#undef REAL_EPS
 #undef REAL_MAX
 
 /* Counter-based synthetic input generator: splitmix64 of

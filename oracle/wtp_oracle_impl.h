@@ -684,6 +684,55 @@ void FN(wtpo_spacing_boundary_layer)(const REAL* xyz, int64_t n, int dim, const 
     }
 }
 
+
+/* ---- isinside: the post-filter of the volume-only repel (src/repel.jl:90) --------------------
+ * 3-D (src/isinside.jl:86-106): g = sum over boundary elements of
+ *   ((area * dist) . normal) / norm(dist)^3,  dist = testpoint - point,
+ * inside iff g < -2*pi (the comparison promotes g to Float64).  A test point coincident with an
+ * element gives 0/0 = NaN, NaN < x is false: outside, as in the reference.  The reference reduces
+ * with tmapreduce (order unspecified); here the sum is sequential, in T. */
+void FN(wtpo_isinside_greens)(const REAL* test, int64_t n, const REAL* pts, const REAL* normals,
+                              const REAL* areas, int64_t m, REAL* g_out, uint8_t* inside) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        const REAL* x = test + 3 * i;
+        REAL g = 0;
+        for (int64_t j = 0; j < m; ++j) {
+            REAL dx = x[0] - pts[3 * j], dy = x[1] - pts[3 * j + 1], dz = x[2] - pts[3 * j + 2];
+            REAL a = areas[j];
+            REAL dot = ((a * dx) * normals[3 * j] + (a * dy) * normals[3 * j + 1]) + (a * dz) * normals[3 * j + 2];
+            REAL r = SQRT((dx * dx + dy * dy) + dz * dz);
+            g = g + dot / ((r * r) * r);
+        }
+        if (g_out) g_out[i] = g;
+        inside[i] = ((double)g < -2.0 * 3.14159265358979323846) ? 1 : 0;
+    }
+}
+
+/* 2-D (src/isinside.jl:17-33): true when the test point coincides with a polygon point
+ * (r < 100 eps); else the sum of the signed angles ∠(p_i, x, p_{i+1}) around the closed,
+ * ordered polygon (Meshes' 2-D ∠(u, v) = atan(u x v, u . v)); inside iff |sum| >= 1e3 eps(T). */
+void FN(wtpo_isinside_winding)(const REAL* test, int64_t n, const REAL* poly, int64_t m, REAL* sum_out,
+                               uint8_t* inside) {
+    const REAL eps = REAL_EPS;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        const REAL x = test[2 * i], y = test[2 * i + 1];
+        int coincident = 0;
+        REAL sum = 0;
+        for (int64_t j = 0; j < m; ++j) {
+            const int64_t jn = j + 1 < m ? j + 1 : 0;
+            REAL ux = poly[2 * j] - x, uy = poly[2 * j + 1] - y;
+            REAL vx = poly[2 * jn] - x, vy = poly[2 * jn + 1] - y;
+            if (SQRT(ux * ux + uy * uy) < (REAL)1.0e2 * eps) coincident = 1;
+            sum = sum + ATAN2(ux * vy - uy * vx, ux * vx + uy * vy);
+        }
+        if (sum_out) sum_out[i] = sum;
+        REAL as = sum < 0 ? -sum : sum;
+        inside[i] = coincident ? 1 : (as < (REAL)1.0e3 * eps ? 0 : 1);
+    }
+}
+
 #undef KD_LEAF
 #undef FN
 #undef CAT

@@ -93,3 +93,38 @@ def test_repel_variable_spacing_and_kick(ctx, wtp):
     assert len(conv) == 5 and np.isfinite(new.volume.points()).all()
     sp2 = wtp.LogLike(cloud.boundary.points(), 0.08, 1.3)
     assert wtp.repel(cloud, sp2, max_iters=2, stall_after=0, ctx=ctx).volume.points().shape == (len(cloud.volume), 3)
+
+
+def test_near_duplicate_keep_mask(O, wtp, ctx):
+    """_near_duplicate_keep_mask over the device radius search: the reference's known answers
+    (test/repel.jl:301-325) and the oracle on a cloud seeded with near-duplicates."""
+    from whatsthepoint_jl_amd.repel import near_duplicate_keep_mask
+
+    pts = np.array([[0, 0, 0], [1, 0, 0], [2, 0, 0], [2.01, 0, 0], [3, 0, 0]], dtype=np.float64)
+    keep = near_duplicate_keep_mask(pts, np.ones(5), 0.5, ctx=ctx)
+    assert keep.tolist() == [True, True, True, False, True]
+    assert near_duplicate_keep_mask(pts, np.ones(5), 0.0, ctx=ctx).all()
+    cluster = np.array([[10.0 + 1.0e-3 * i, 0, 0] for i in range(1, 13)])
+    cp = np.concatenate([pts, cluster])
+    ck = near_duplicate_keep_mask(cp, np.ones(len(cp)), 0.5, ctx=ctx)
+    assert ck[5] and ck[5:].sum() == 1
+    rng = np.random.default_rng(12)
+    for dtype in (np.float32, np.float64):
+        x = wtp.synth.uniform(6000, 3, dtype, 9)
+        dup = rng.choice(6000, 300, replace=False)
+        x = np.concatenate([x, (x[dup] + rng.normal(0, 0.004, (300, 3))).astype(dtype)])
+        sp = (0.04 + 0.03 * x[:, 0]).astype(dtype)                   # variable spacing: thresholds differ per point
+        got = near_duplicate_keep_mask(x, sp, 0.4, ctx=ctx)
+        want = O.cull_mask(x, sp, 0.4)
+        assert np.array_equal(got, want) and 150 < (~got).sum() < 1500
+
+
+def test_repel_cull_ratio(O, wtp, ctx):
+    b = wtp.synth.uniform(300, 3, np.float32, 2)
+    v = wtp.synth.uniform(2000, 3, np.float32, 4)
+    cloud = wtp.PointCloud(wtp.PointBoundary(b), wtp.PointVolume(v))
+    kw = dict(max_iters=2, stall_after=0, tol=0.0, inside=lambda p: np.ones(len(p), bool), ctx=ctx)
+    everyone = wtp.repel(cloud, wtp.ConstantSpacing(0.08), **kw).volume.points()
+    culled = wtp.repel(cloud, wtp.ConstantSpacing(0.08), cull_ratio=0.6, **kw).volume.points()
+    want = O.cull_mask(everyone, np.full(len(everyone), 0.08, np.float32), 0.6)   # src/repel.jl:91-93
+    assert np.array_equal(culled, everyone[want]) and 20 < (~want).sum() < 1500

@@ -46,7 +46,20 @@ def sweep_case(name, n, n_fixed, dim, dtype, k, force, seed):
                         forces=r["forces"], nn_dist=r["nn_dist"], nn_id=r["nn_id"])
 
 
+def box_surface(name="box_surface"):
+    """Boundary elements of the reference's own test surface (test/data/box.stl, a data file its
+    tests hold: test/isinside.jl:59-73, TestData.BOX_PATH): centroid, unit normal, area per face.
+    The STL itself cannot travel to the GPU box; this fixture does."""
+    path = "/root/reference/test/data/box.stl"
+    if not os.path.exists(path):
+        print("box.stl not mounted: keeping the committed", name)
+        return
+    c, nrm, a = wtp_amd.stl.surface_elements(path, np.float32)
+    np.savez_compressed(os.path.join(OUT, name), centroid=c, normal=nrm, area=a)
+
+
 if __name__ == "__main__":
+    box_surface()
     knn_case("knn_f32_3d_k21.npz", 2000, 3, np.float32, 21, False, 101)
     knn_case("knn_f32_3d_k22_self.npz", 2000, 3, np.float32, 22, True, 102)
     knn_case("knn_f64_2d_k5.npz", 1500, 2, np.float64, 5, False, 103)

@@ -14,6 +14,7 @@ from .forces import (RepelForceModel, InverseDistanceForce, SpacingEquilibriumFo
 from .spacings import ConstantSpacing, LogLike, BoundaryLayerSpacing
 from .repel import repel, relax
 from .metrics import metrics, spacing_metrics, spacing_fidelity_metrics
+from .inside import isinside
 from . import synth, stl
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -64,6 +64,8 @@ SIGNATURES = {
     "wtp_relax_revert": (_i, [_vp]),
     "wtp_relax_set_spacing": (_i, [_vp, _vp]),
     "wtp_relax_end": (_i, [_vp]),
+    "wtp_isinside_greens": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _vp, _vp]),
+    "wtp_isinside_winding": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _vp, _vp]),
     "wtp_set_stream": (_i, [_vp, _vp, _i]),
     "wtp_relax_layers_dev": (_i, [_vp, _i, _d, _d, _d, _d, _vp, _vp, _i64, C.POINTER(_i64)]),
     "wtp_relax_set_fixed_dev": (_i, [_vp, _vp, _i64]),

@@ -1,7 +1,9 @@
 """Point containers — only what the hot path touches (src/surface.jl:167-205,
 src/boundary.jl:164, src/volume.jl:97-125, src/cloud.jl:178-237): coordinates as numpy
 arrays, `points()` = boundary first then volume (the global index space), and the functional
-`set_topology` / in-place `rebuild_topology` verbs.  Normals, areas, units, I/O stay in Julia."""
+`set_topology` / in-place `rebuild_topology` verbs.  Surfaces optionally carry the per-point
+normals and areas the `isinside` filter of `repel` integrates over (src/isinside.jl:86-106);
+units and I/O stay in Julia."""
 from __future__ import annotations
 
 from collections import OrderedDict
@@ -55,8 +57,18 @@ class _HasTopology:
 
 
 class PointSurface(_HasTopology):
-    def __init__(self, points, topology=None):
+    def __init__(self, points, normals=None, areas=None, topology=None):
+        """PointSurface(points[, normals, areas]) — src/surface.jl: one (point, normal, area)
+        element per boundary point."""
+        if isinstance(normals, T.AbstractTopology) and areas is None and topology is None:
+            normals, topology = None, normals  # PointSurface(points, topology)
         self._points = _as_points(points)
+        self.normals = None if normals is None else _as_points(normals, self._points.dtype)
+        self.areas = None if areas is None else np.ascontiguousarray(areas, dtype=self._points.dtype).reshape(-1)
+        if self.normals is not None and self.normals.shape != self._points.shape:
+            raise ValueError("normals must match points")
+        if self.areas is not None and self.areas.shape != (len(self._points),):
+            raise ValueError("areas must be one value per point")
         self.topology = topology or T.NoTopology()
 
     def points(self):
@@ -66,7 +78,7 @@ class PointSurface(_HasTopology):
         return len(self._points)
 
     def _with(self, topo):
-        return PointSurface(self._points, topo)
+        return PointSurface(self._points, self.normals, self.areas, topo)
 
 
 class PointVolume(_HasTopology):
@@ -87,13 +99,30 @@ class PointVolume(_HasTopology):
 class PointBoundary:
     """Named surfaces; points(boundary) concatenates them in insertion order (src/boundary.jl:164)."""
 
-    def __init__(self, points=None, name: str = "surface1", surfaces=None):
+    def __init__(self, points=None, normals=None, areas=None, name: str = "surface1", surfaces=None):
         self.surfaces = OrderedDict()
+        if isinstance(normals, str) and areas is None:
+            normals, name = None, normals  # PointBoundary(points, name)
         if surfaces is not None:
             for k, v in surfaces.items():
                 self.surfaces[k] = v if isinstance(v, PointSurface) else PointSurface(v)
         elif points is not None:
-            self.surfaces[name] = points if isinstance(points, PointSurface) else PointSurface(points)
+            self.surfaces[name] = points if isinstance(points, PointSurface) else PointSurface(points, normals, areas)
+
+    @classmethod
+    def from_stl(cls, path: str, dtype=np.float32, name: str = "surface1"):
+        """PointBoundary(filepath, unit) (src/io.jl:36-56): one element per face."""
+        from . import stl
+
+        return cls(PointSurface(*stl.surface_elements(path, dtype)), name=name)
+
+    def elements(self):
+        """(points, normals, areas) over all surfaces, or None if a surface lacks normals/areas."""
+        ss = list(self.surfaces.values())
+        if not ss or any(s.normals is None or s.areas is None for s in ss):
+            return None
+        return (np.concatenate([s.points() for s in ss]), np.concatenate([s.normals for s in ss]),
+                np.concatenate([s.areas for s in ss]))
 
     def points(self):
         parts = [s.points() for s in self.surfaces.values()]

@@ -234,7 +234,8 @@ WTP_API int wtp_destroy(wtp_ctx* ctx) {
                       &ctx->cell_cnt, &ctx->cell_start, &ctx->scan_tmp, &ctx->grid, &ctx->bbox_part,
                       &ctx->idx_out, &ctx->dist_out, &ctx->counts_out, &ctx->forces, &ctx->nn_dist,
                       &ctx->nn_id, &ctx->spacing_pp, &ctx->partials, &ctx->stats, &ctx->fb_list,
-                      &ctx->fb_count, &ctx->fb2_list, &ctx->fb2_count, &ctx->scratch, &ctx->diag};
+                      &ctx->fb_count, &ctx->fb2_list, &ctx->fb2_count, &ctx->scratch, &ctx->diag,
+                      &ctx->ins_in, &ctx->ins_elems, &ctx->ins_partial, &ctx->ins_out};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     if (ctx->host_pinned) hipHostFree(ctx->host_pinned);
@@ -734,6 +735,87 @@ WTP_API int wtp_relax_end(wtp_ctx* ctx) {
     if (!ctx) return WTP_ERR_ARG;
     ctx->relax = RelaxState{};
     return WTP_OK;
+}
+
+// ---- isinside post-filter (src/repel.jl:90) ------------------------------------------------------------
+static size_t align256(size_t b) { return (b + 255) / 256 * 256; }
+
+WTP_API int wtp_isinside_greens(wtp_ctx* ctx, const void* test_xyz, int64_t n, const void* elem_xyz,
+                                const void* elem_normal, const void* elem_area, int64_t m, int dtype,
+                                uint8_t* inside_out, void* g_out) {
+    if (!ctx) return WTP_ERR_ARG;
+    if (dtype != WTP_F32 && dtype != WTP_F64) return fail(ctx, WTP_ERR_ARG, "dtype must be WTP_F32 or WTP_F64");
+    if (n < 0 || m < 1) return fail(ctx, WTP_ERR_ARG, "need n >= 0 test points and m >= 1 boundary elements");
+    if (n > 2000000000LL || m > 2000000000LL) return fail(ctx, WTP_ERR_ARG, "n or m exceeds the int32 index space");
+    if (n == 0) return WTP_OK;
+    if (!test_xyz || !elem_xyz || !elem_normal || !elem_area || !inside_out)
+        return fail(ctx, WTP_ERR_ARG, "NULL array");
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t ts = tsize(dtype);
+    const int chunks = isinside_chunks(ctx, n, m, isinside_greens_ppb());
+    // ins_in: [test n*3 | p m*3 | normal m*3 | area m]; ins_out: [g n | inside n]
+    const size_t o_p = align256(ts * n * 3), o_n = o_p + align256(ts * m * 3), o_a = o_n + align256(ts * m * 3);
+    int rc;
+    if ((rc = ensure(ctx, ctx->ins_in, o_a + ts * m))) return rc;
+    if ((rc = ensure(ctx, ctx->ins_elems, isinside_elem_bytes(dtype) * (size_t)m))) return rc;
+    if ((rc = ensure(ctx, ctx->ins_partial, ts * (size_t)n * chunks))) return rc;
+    if ((rc = ensure(ctx, ctx->ins_out, align256(ts * n) + (size_t)n))) return rc;
+    char* in = (char*)ctx->ins_in.p;
+    char* out = (char*)ctx->ins_out.p;
+    WTP_HIP(ctx, hipMemcpyAsync(in, test_xyz, ts * n * 3, hipMemcpyHostToDevice, ctx->stream));
+    WTP_HIP(ctx, hipMemcpyAsync(in + o_p, elem_xyz, ts * m * 3, hipMemcpyHostToDevice, ctx->stream));
+    WTP_HIP(ctx, hipMemcpyAsync(in + o_n, elem_normal, ts * m * 3, hipMemcpyHostToDevice, ctx->stream));
+    WTP_HIP(ctx, hipMemcpyAsync(in + o_a, elem_area, ts * m, hipMemcpyHostToDevice, ctx->stream));
+    uint8_t* d_inside = (uint8_t*)(out + align256(ts * n));
+    int sp = span_begin(ctx, 2);
+    if (dtype == WTP_F32)
+        rc = launch_isinside_greens<float>(ctx, (const float*)in, n, (const float*)(in + o_p), (const float*)(in + o_n),
+                                           (const float*)(in + o_a), m, ctx->ins_elems.p, chunks,
+                                           (float*)ctx->ins_partial.p, (float*)out, d_inside);
+    else
+        rc = launch_isinside_greens<double>(ctx, (const double*)in, n, (const double*)(in + o_p),
+                                            (const double*)(in + o_n), (const double*)(in + o_a), m, ctx->ins_elems.p,
+                                            chunks, (double*)ctx->ins_partial.p, (double*)out, d_inside);
+    span_end(ctx, sp);
+    if (rc) return rc;
+    WTP_HIP(ctx, hipMemcpyAsync(inside_out, d_inside, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    if (g_out) WTP_HIP(ctx, hipMemcpyAsync(g_out, out, ts * n, hipMemcpyDeviceToHost, ctx->stream));
+    return sync(ctx);
+}
+
+WTP_API int wtp_isinside_winding(wtp_ctx* ctx, const void* test_xy, int64_t n, const void* poly_xy, int64_t m,
+                                 int dtype, uint8_t* inside_out, void* sum_out) {
+    if (!ctx) return WTP_ERR_ARG;
+    if (dtype != WTP_F32 && dtype != WTP_F64) return fail(ctx, WTP_ERR_ARG, "dtype must be WTP_F32 or WTP_F64");
+    if (m < 3) return fail(ctx, WTP_ERR_ARG, "need at least 3 points to define a polygon"); // src/isinside.jl:38-43
+    if (n < 0 || n > 2000000000LL || m > 2000000000LL) return fail(ctx, WTP_ERR_ARG, "bad n or m");
+    if (n == 0) return WTP_OK;
+    if (!test_xy || !poly_xy || !inside_out) return fail(ctx, WTP_ERR_ARG, "NULL array");
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t ts = tsize(dtype);
+    const int chunks = isinside_chunks(ctx, n, m, isinside_winding_ppb());
+    const size_t o_p = align256(ts * n * 2);
+    int rc;
+    if ((rc = ensure(ctx, ctx->ins_in, o_p + ts * m * 2))) return rc;
+    if ((rc = ensure(ctx, ctx->ins_partial, ts * (size_t)n * chunks))) return rc;
+    if ((rc = ensure(ctx, ctx->ins_elems, sizeof(int32_t) * (size_t)n))) return rc; // coincidence flags
+    if ((rc = ensure(ctx, ctx->ins_out, align256(ts * n) + (size_t)n))) return rc;
+    char* in = (char*)ctx->ins_in.p;
+    char* out = (char*)ctx->ins_out.p;
+    WTP_HIP(ctx, hipMemcpyAsync(in, test_xy, ts * n * 2, hipMemcpyHostToDevice, ctx->stream));
+    WTP_HIP(ctx, hipMemcpyAsync(in + o_p, poly_xy, ts * m * 2, hipMemcpyHostToDevice, ctx->stream));
+    uint8_t* d_inside = (uint8_t*)(out + align256(ts * n));
+    if (dtype == WTP_F32)
+        rc = launch_isinside_winding<float>(ctx, (const float*)in, n, (const float*)(in + o_p), m, chunks,
+                                            (float*)ctx->ins_partial.p, (int32_t*)ctx->ins_elems.p, (float*)out, d_inside);
+    else
+        rc = launch_isinside_winding<double>(ctx, (const double*)in, n, (const double*)(in + o_p), m, chunks,
+                                             (double*)ctx->ins_partial.p, (int32_t*)ctx->ins_elems.p, (double*)out,
+                                             d_inside);
+    if (rc) return rc;
+    WTP_HIP(ctx, hipMemcpyAsync(inside_out, d_inside, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    if (sum_out) WTP_HIP(ctx, hipMemcpyAsync(sum_out, out, ts * n, hipMemcpyDeviceToHost, ctx->stream));
+    return sync(ctx);
 }
 
 // ---- sharded sessions ---------------------------------------------------------------------------------

@@ -44,6 +44,9 @@ namespace wtp {
 constexpr int NB = 64;          // per-lane candidate ring / sorting-network width
 constexpr int kFastKMax = 32;   // k >= this goes to the wave kernel
 constexpr int kOwnRows = BY * BZ;
+#ifndef WTP_LANE_ROWS
+#define WTP_LANE_ROWS 0 // CS sweep: 1 = every lane walks its 9 candidate rows at its own pace
+#endif
 #ifndef WTP_SCAN_U
 #define WTP_SCAN_U 8
 #endif
@@ -424,8 +427,42 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
                 ea = (uint32_t)sm->hstart[base + 3] * 16u;
             }
             uint32_t kth = 0, next = 0;
+            int rbase_l = ((hz - 1) * HY + (hy - 1)) * HX + (hx - 1); // CS lane rows: hstart index of my row
             for (;;) {
                 bool pressure = false;
+                if (CS && WTP_LANE_ROWS) {
+                    // Every lane advances to its next row as soon as its current one is exhausted,
+                    // so the wave runs for max over lanes of (sum of row lengths) steps instead of
+                    // sum over rows of (max over lanes).
+                    while (__any(row < 9)) {
+                        if (__any(ra > full_b)) {
+                            pressure = true;
+                            break;
+                        }
+                        f4 c[SU];
+                        lds_read_group(c, lds_base + pa);
+#pragma unroll
+                        for (int u = 0; u < SU; ++u) {
+                            const float ex = qp.x - c[u].x, ey = qp.y - c[u].y, ez = qp.z - c[u].z;
+                            const float d = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
+                            const float tl = (pa + 16u * u < ea) ? tau_s : -1.f;
+                            const bool take = d <= tl;
+                            *reinterpret_cast<uint16_t*>(smem_raw + (take ? ra : dump_b)) = (uint16_t)(pa + 16u * u);
+                            ra += take ? (kBrickThreads * 2u) : 0u;
+                        }
+                        pa += 16u * SU;
+                        while (pa >= ea && row < 9) { // next non-empty row of this lane
+                            ++row;
+                            if (row < 9) {
+                                rbase_l += (row % 3 == 0) ? (HY * HX - 2 * HX) : HX;
+                                pa = (uint32_t)sm->hstart[rbase_l] * 16u;
+                                ea = (uint32_t)sm->hstart[rbase_l + 3] * 16u;
+                            } else {
+                                pa = ea = 0u; // done: reads stay at the start of the point area, all masked
+                            }
+                        }
+                    }
+                } else
                 while (row < 9) {
                     // SCAN_U candidates per step: all reads issued together (one wait), then
                     // branch-free appends.  Reads past the run end stay inside the padded point

@@ -167,6 +167,7 @@ struct wtp_ctx {
     wtp::DevBuf partials, stats, fb_list, fb_count, fb2_list, fb2_count;
     wtp::DevBuf scratch;       // misc (relax_get staging, radius rows)
     wtp::DevBuf diag;          // diagnostic builds only
+    wtp::DevBuf ins_in, ins_elems, ins_partial, ins_out; // isinside filter
     void* host_pinned = nullptr;
     size_t host_pinned_cap = 0;
     // radius two-phase state
@@ -242,6 +243,17 @@ template <typename T>
 int launch_set_point(wtp_ctx* ctx, Pt<T>* pts, int64_t n, int32_t id, int dim, const T* d_xyz3);
 template <typename T>
 int launch_gen_uniform(wtp_ctx* ctx, uint64_t seed, int64_t first, int64_t n, int dim, T* d_out);
+// isinside post-filter (wtp_inside.hip)
+int isinside_chunks(wtp_ctx* ctx, int64_t n, int64_t m, int points_per_block);
+int isinside_greens_ppb();
+int isinside_winding_ppb();
+size_t isinside_elem_bytes(int dtype);
+template <typename T>
+int launch_isinside_greens(wtp_ctx* ctx, const T* d_test, int64_t n, const T* d_p, const T* d_nrm, const T* d_area,
+                           int64_t m, void* d_elems, int chunks, T* d_partial, T* d_g, uint8_t* d_inside);
+template <typename T>
+int launch_isinside_winding(wtp_ctx* ctx, const T* d_test, int64_t n, const T* d_poly, int64_t m, int chunks,
+                            T* d_partial, int32_t* d_coincident, T* d_sum, uint8_t* d_inside);
 // sharded sessions: boundary layers of the movable points / replacement of the fixed head
 int layer_blocks(int64_t n);
 template <typename T>

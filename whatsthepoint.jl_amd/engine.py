@@ -103,6 +103,41 @@ class Context:
     def relax(self, snap, n_fixed: int, spacing, force, k: int, alpha_lo: float, alpha_max: float, device_ptr=None):
         return RelaxSession(self, snap, n_fixed, spacing, force, k, alpha_lo, alpha_max, device_ptr=device_ptr)
 
+    # ---- isinside post-filter (src/repel.jl:90; src/isinside.jl) -------------------------------
+    def isinside_greens(self, test, elem_xyz, elem_normal, elem_area, return_g: bool = False):
+        """3-D: bool[n] (and g[n]) for test points against boundary elements (centroid, normal, area)."""
+        test = _cloud(test)
+        if test.shape[1] != 3:
+            raise L.WtpArgumentError("the Green's-function test is 3-D")
+        dt = test.dtype
+        p = np.ascontiguousarray(elem_xyz, dtype=dt)
+        nrm = np.ascontiguousarray(elem_normal, dtype=dt)
+        a = np.ascontiguousarray(elem_area, dtype=dt).reshape(-1)
+        if p.ndim != 2 or p.shape[1] != 3 or nrm.shape != p.shape or a.shape != (len(p),):
+            raise L.WtpArgumentError("boundary elements need (m, 3) points, (m, 3) normals and m areas")
+        inside = np.zeros(len(test), dtype=np.uint8)
+        g = np.zeros(len(test), dtype=dt) if return_g else None
+        rc = self._lib.wtp_isinside_greens(self._h, _vp(test), len(test), _vp(p), _vp(nrm), _vp(a), len(p),
+                                           _dtype_code(dt), _vp(inside), _vp(g))
+        L.check(self._h, rc)
+        return (inside.astype(bool), g) if return_g else inside.astype(bool)
+
+    def isinside_winding(self, test, poly, return_sum: bool = False):
+        """2-D: bool[n] (and angle sums) for test points against an ordered, closed polygon."""
+        test = _cloud(test)
+        if test.shape[1] != 2:
+            raise L.WtpArgumentError("the winding-number test is 2-D")
+        dt = test.dtype
+        poly = np.ascontiguousarray(poly, dtype=dt)
+        if poly.ndim != 2 or poly.shape[1] != 2:
+            raise L.WtpArgumentError("polygon must be (m, 2)")
+        inside = np.zeros(len(test), dtype=np.uint8)
+        s = np.zeros(len(test), dtype=dt) if return_sum else None
+        rc = self._lib.wtp_isinside_winding(self._h, _vp(test), len(test), _vp(poly), len(poly), _dtype_code(dt),
+                                            _vp(inside), _vp(s))
+        L.check(self._h, rc)
+        return (inside.astype(bool), s) if return_sum else inside.astype(bool)
+
     def set_stream(self, stream_handle=None):
         """Run the library on a caller-owned HIP stream (handle as an int; 0 = the device's default
         stream, which is torch's current stream unless the caller switched); None = own stream."""

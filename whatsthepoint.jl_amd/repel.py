@@ -3,8 +3,9 @@
 The sweep (k-NN rebuild + force + step + reductions) runs on the GPU through libwtp; this
 module keeps what the reference keeps on the calling thread: defaults, argument checks, the stop
 rules of src/repel.jl:305-334, the kick (:415-433) and the closest-pair trace (:294-296).
-Out of scope here: the `isinside` post-filter (src/repel.jl:90) and the octree
-wall rule (:448-537) — pass `inside=` to filter survivors yourself."""
+The `isinside` post-filter (src/repel.jl:90) runs on the GPU as well (inside.py); the cull
+(:91-93) takes its candidate pairs from the device radius search.  Out of scope here
+(SURVEY.md §8f): the octree wall rule (:448-537)."""
 from __future__ import annotations
 
 import logging
@@ -123,6 +124,46 @@ def _maybe_kick(sess, pair, state, kick_after, spacings, n_fixed, n_protected, r
     return dict(pair=(a, b), rs=pair["r_over_s"], count=0), True
 
 
+def near_duplicate_keep_mask(pts, spacings, ratio, ctx=None):
+    """_near_duplicate_keep_mask (src/repel.jl:565-580): greedy, order-preserving keep-mask — a kept
+    point i drops every still-kept point closer than ratio*spacings[i].  The ball search at the
+    largest cull radius is the device radius search (CSR rows of every point within
+    ratio*max(spacings), inclusive); the greedy pass walks only the rows that are not empty."""
+    pts = np.ascontiguousarray(pts)
+    n = len(pts)
+    keep = np.ones(n, dtype=bool)
+    if ratio <= 0 or n < 2:
+        return keep
+    spacings = np.asarray(spacings, dtype=pts.dtype).reshape(-1)
+    if spacings.shape != (n,):
+        spacings = np.broadcast_to(spacings, (n,))
+    ctx = ctx or default_context()
+    offsets, idx = ctx.radius(pts, float(ratio) * float(spacings.max()))
+    for i in np.nonzero(np.diff(offsets))[0]:           # ascending i, like the reference's loop
+        if not keep[i]:
+            continue
+        js = idx[offsets[i]:offsets[i + 1]].astype(np.int64)
+        js = js[keep[js]]
+        if len(js) == 0:
+            continue
+        d = pts[js] - pts[i]
+        r = np.sqrt((d * d).sum(axis=1, dtype=pts.dtype))
+        keep[js[r < pts.dtype.type(ratio) * spacings[i]]] = False
+    return keep
+
+
+def cull(pts, spacing, ratio, ctx=None):
+    """_cull (src/repel.jl:549-555): the keep-mask plus the defect warning."""
+    sv, const = _spacing_values(spacing, np.asarray(pts))
+    sp = np.full(len(pts), sv, dtype=np.asarray(pts).dtype) if const else sv
+    keep = near_duplicate_keep_mask(pts, sp, ratio, ctx=ctx)
+    n_culled = int((~keep).sum())
+    if n_culled > 0:
+        log.warning("Cull removed %d near-duplicate point(s) — repel left defects behind (cull_ratio=%g)",
+                    n_culled, ratio)
+    return keep
+
+
 def repel(cloud: PointCloud, spacing, *, beta=0.2, force_model: RepelForceModel = None, alpha=None,
           alpha_min=None, k=21, max_iters=1000, tol=1.0e-6, rebuild_every=1, cull_ratio=0.0, kick_after=0,
           stall_after=50, cv_target=0.0, convergence=None, trace=None, inside=None, ctx=None):
@@ -145,7 +186,15 @@ def repel(cloud: PointCloud, spacing, *, beta=0.2, force_model: RepelForceModel 
                       cv_target=cv_target, trace=trace, n_protected=len(bnd_p), ctx=ctx)
     if convergence is not None:
         convergence.extend(conv)
-    survivors = out if inside is None else out[np.asarray(inside(out), dtype=bool)]
+    # survivors = filter(x -> isinside(x, cloud), p)   (src/repel.jl:90)
+    if inside is not None:                 # caller's own containment test
+        survivors = out[np.asarray(inside(out), dtype=bool)]
+    elif len(out) and (out.shape[1] == 2 or cloud.boundary.elements() is not None):
+        from .inside import isinside
+
+        survivors = out[isinside(out, cloud, ctx=ctx)]
+    else:                                  # a bare point boundary (no normals/areas): nothing to integrate
+        survivors = out
     if cull_ratio > 0 and len(survivors):
-        raise NotImplementedError("cull_ratio > 0: _near_duplicate_keep_mask is SURVEY.md §8f (next)")
+        survivors = survivors[cull(survivors, spacing, cull_ratio, ctx=ctx)]
     return PointCloud(cloud.boundary, PointVolume(survivors), T.NoTopology())
