@@ -63,14 +63,23 @@ typedef struct wtp_force_desc {
  * (src/repel.jl:209,251,260). */
 typedef enum wtp_spacing_kind {
     WTP_SPACING_CONSTANT = 0,  /* ConstantSpacing: spacings.jl:35-39 */
-    WTP_SPACING_PER_POINT = 1  /* host-evaluated s[n] in snapshot order; refresh with
-                                  wtp_relax_set_spacing (variable spacings; §8f item 3) */
+    WTP_SPACING_PER_POINT = 1, /* host-evaluated s[n] in snapshot order (any callable); refresh with
+                                  wtp_relax_set_spacing */
+    WTP_SPACING_LOGLIKE = 2,   /* LogLike: spacings.jl:67-72, p0 = base_size, p1 = growth_rate       */
+    WTP_SPACING_BOUNDARY_LAYER = 3 /* BoundaryLayerSpacing: spacings.jl:121-133, p0 = at_wall,
+                                  p1 = bulk, p2 = layer_thickness                                 */
 } wtp_spacing_kind;
 
 typedef struct wtp_spacing_desc {
     int32_t kind;            /* wtp_spacing_kind */
     double constant;         /* CONSTANT: the spacing (unitless, as ustrip gives it) */
     const void* per_point;   /* PER_POINT: host array of n values of the cloud's dtype */
+    double p0, p1, p2;       /* LOGLIKE / BOUNDARY_LAYER parameters (unitless)          */
+    const void* boundary_xyz;/* LOGLIKE / BOUNDARY_LAYER: host array, n_boundary x dim of the cloud's dtype:
+                                the points the law measures its distance to (spacings.jl:17-28); they
+                                are evaluated on the device at every point's current position, every
+                                sweep (src/repel.jl:251,260) */
+    int64_t n_boundary;
 } wtp_spacing_desc;
 
 /* Scalars the host-side stop logic of src/repel.jl:293-334 needs after one sweep. */
@@ -170,6 +179,16 @@ int wtp_relax_revert(wtp_ctx* ctx);
 int wtp_relax_set_spacing(wtp_ctx* ctx, const void* spacing);
 /* Release the relax state (device buffers stay pooled in the context). */
 int wtp_relax_end(wtp_ctx* ctx);
+
+/* The spacings the session currently holds, one value per snapshot point in snapshot order
+ * (`spacings` of src/repel.jl:209,251 — the kick and the trace read it).  Host array of n values. */
+int wtp_relax_get_spacing(wtp_ctx* ctx, void* spacing_out);
+
+/* A variable spacing law evaluated at arbitrary points (spacing.(points), e.g. the default
+ * alpha = minimum(spacing.(to(cloud)))/20 of src/repel.jl:61, or the metrics): LOGLIKE /
+ * BOUNDARY_LAYER descriptors only.  xyz: host n x dim of dtype, out: host n values.  */
+int wtp_spacing_eval(wtp_ctx* ctx, const wtp_spacing_desc* spacing, const void* xyz, int64_t n, int dim,
+                     int dtype, void* out);
 
 /* ---- isinside: the post-filter of the volume-only repel (src/repel.jl:90) -----------------
  * 3-D, replaces isinside(testpoint, cloud|boundary) + _greens (src/isinside.jl:86-106) for a whole

@@ -12,6 +12,7 @@ SO_PATH = os.environ.get("WTP_LIB") or os.path.join(CSRC, "libwtp.so")
 
 WTP_OK, WTP_ERR_ARG, WTP_ERR_OOM, WTP_ERR_HIP, WTP_ERR_STATE, WTP_ERR_NO_DEVICE = range(6)
 WTP_F32, WTP_F64 = 0, 1
+WTP_SPACING_CONSTANT, WTP_SPACING_PER_POINT, WTP_SPACING_LOGLIKE, WTP_SPACING_BOUNDARY_LAYER = range(4)
 
 
 class WtpError(RuntimeError):
@@ -31,7 +32,9 @@ class ForceDesc(C.Structure):
 
 
 class SpacingDesc(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("constant", C.c_double), ("per_point", C.c_void_p)]
+    _fields_ = [("kind", C.c_int32), ("constant", C.c_double), ("per_point", C.c_void_p),
+                ("p0", C.c_double), ("p1", C.c_double), ("p2", C.c_double),
+                ("boundary_xyz", C.c_void_p), ("n_boundary", C.c_int64)]
 
 
 class StepStats(C.Structure):
@@ -64,6 +67,8 @@ SIGNATURES = {
     "wtp_relax_revert": (_i, [_vp]),
     "wtp_relax_set_spacing": (_i, [_vp, _vp]),
     "wtp_relax_end": (_i, [_vp]),
+    "wtp_relax_get_spacing": (_i, [_vp, _vp]),
+    "wtp_spacing_eval": (_i, [_vp, C.POINTER(SpacingDesc), _vp, _i64, _i, _i, _vp]),
     "wtp_isinside_greens": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _vp, _vp]),
     "wtp_isinside_winding": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _vp, _vp]),
     "wtp_set_stream": (_i, [_vp, _vp, _i]),

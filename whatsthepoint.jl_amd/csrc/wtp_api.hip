@@ -235,7 +235,7 @@ WTP_API int wtp_destroy(wtp_ctx* ctx) {
                       &ctx->idx_out, &ctx->dist_out, &ctx->counts_out, &ctx->forces, &ctx->nn_dist,
                       &ctx->nn_id, &ctx->spacing_pp, &ctx->partials, &ctx->stats, &ctx->fb_list,
                       &ctx->fb_count, &ctx->fb2_list, &ctx->fb2_count, &ctx->scratch, &ctx->diag,
-                      &ctx->ins_in, &ctx->ins_elems, &ctx->ins_partial, &ctx->ins_out};
+                      &ctx->ins_in, &ctx->ins_elems, &ctx->ins_partial, &ctx->ins_out, &ctx->kd_nodes, &ctx->sp_hint};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     if (ctx->host_pinned) hipHostFree(ctx->host_pinned);
@@ -383,6 +383,48 @@ WTP_API int wtp_radius_fill(wtp_ctx* ctx, const int64_t* offsets, int32_t* idx_o
     return sync(ctx);
 }
 
+// ---- variable spacings: kd-tree over the law's boundary points, cached per context -----------------
+static bool spacing_on_device(int kind) { return kind == WTP_SPACING_LOGLIKE || kind == WTP_SPACING_BOUNDARY_LAYER; }
+
+static int check_spacing_law(wtp_ctx* ctx, const wtp_spacing_desc* s) {
+    if (!s->boundary_xyz || s->n_boundary < 1)
+        return fail(ctx, WTP_ERR_ARG, "boundary_points must be non-empty"); // spacings.jl:61-62,106-107
+    if (s->n_boundary > 2000000000LL) return fail(ctx, WTP_ERR_ARG, "n_boundary exceeds the int32 index space");
+    if (s->kind == WTP_SPACING_BOUNDARY_LAYER && !(s->p2 > 0))
+        return fail(ctx, WTP_ERR_ARG, "layer_thickness must be positive"); // spacings.jl:108-109
+    return WTP_OK;
+}
+
+static int ensure_kd(wtp_ctx* ctx, const wtp_spacing_desc* s, int dim, int dtype) {
+    const size_t ts = tsize(dtype);
+    const size_t bytes = ts * (size_t)s->n_boundary * dim;
+    uint64_t h = 1469598103934665603ull; // FNV-1a over the coordinates: same boundary -> same tree
+    const unsigned char* b = (const unsigned char*)s->boundary_xyz;
+    for (size_t i = 0; i < bytes; ++i) h = (h ^ b[i]) * 1099511628211ull;
+    if (ctx->kd_m == s->n_boundary && ctx->kd_key == h && ctx->kd_dim == dim && ctx->kd_dtype == dtype) return WTP_OK;
+    const size_t kdsz = dtype == WTP_F32 ? kd_bytes<float>(s->n_boundary) : kd_bytes<double>(s->n_boundary);
+    int rc;
+    if ((rc = ensure(ctx, ctx->kd_nodes, kdsz))) return rc;
+    std::vector<char> host(kdsz);
+    if (dtype == WTP_F32)
+        kd_build_host<float>((const float*)s->boundary_xyz, s->n_boundary, dim, host.data());
+    else
+        kd_build_host<double>((const double*)s->boundary_xyz, s->n_boundary, dim, host.data());
+    WTP_HIP(ctx, hipMemcpyAsync(ctx->kd_nodes.p, host.data(), host.size(), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = sync(ctx))) return rc; // `host` dies with this scope
+    ctx->kd_m = s->n_boundary;
+    ctx->kd_key = h;
+    ctx->kd_dim = dim;
+    ctx->kd_dtype = dtype;
+    return WTP_OK;
+}
+
+// upper bound of a law's values (sizes the compact-support grid; need not be attained)
+static double spacing_law_max(const wtp_spacing_desc* s) {
+    if (s->kind == WTP_SPACING_LOGLIKE) return s->p0;
+    return s->p0 > s->p1 ? s->p0 : s->p1;
+}
+
 // ---- repel ------------------------------------------------------------------------------------------
 static int pick_free(const RelaxState& r, int avoid_a, int avoid_b) {
     for (int i = 0; i < 3; ++i)
@@ -405,6 +447,8 @@ static int relax_init_impl(wtp_ctx* ctx, const void* snap_xyz, bool on_device, i
         if (!(spacing->constant > 0)) return fail(ctx, WTP_ERR_ARG, "constant spacing must be > 0");
     } else if (spacing->kind == WTP_SPACING_PER_POINT) {
         if (!spacing->per_point) return fail(ctx, WTP_ERR_ARG, "per_point spacing array is NULL");
+    } else if (spacing_on_device(spacing->kind)) {
+        if ((rc = check_spacing_law(ctx, spacing))) return rc;
     } else {
         return fail(ctx, WTP_ERR_ARG, "unknown spacing kind");
     }
@@ -441,6 +485,22 @@ static int relax_init_impl(wtp_ctx* ctx, const void* snap_xyz, bool on_device, i
         WTP_HIP(ctx, hipMemcpyAsync(ctx->spacing_pp.p, spacing->per_point, ts * (size_t)n, hipMemcpyHostToDevice,
                                     ctx->stream));
     }
+    if (spacing_on_device(spacing->kind)) {
+        // spacings = spacing.(snap) (src/repel.jl:209): every snapshot point once, the wall included
+        if ((rc = ensure_kd(ctx, spacing, dim, dtype))) return rc;
+        if ((rc = ensure(ctx, ctx->spacing_pp, ts * (size_t)n))) return rc;
+        if ((rc = ensure(ctx, ctx->sp_hint, sizeof(int32_t) * (size_t)n))) return rc;
+        WTP_HIP(ctx, hipMemsetAsync(ctx->sp_hint.p, 0xFF, sizeof(int32_t) * (size_t)n, ctx->stream)); // -1: no hint
+        if (dtype == WTP_F32)
+            rc = launch_spacing_session<float>(ctx, (const float4*)ctx->pts[0].p, n, 0, ctx->kd_nodes.p, ctx->kd_m,
+                                               spacing->kind, spacing->p0, spacing->p1, spacing->p2,
+                                               (float*)ctx->spacing_pp.p, (int32_t*)ctx->sp_hint.p);
+        else
+            rc = launch_spacing_session<double>(ctx, (const double4*)ctx->pts[0].p, n, 0, ctx->kd_nodes.p, ctx->kd_m,
+                                                spacing->kind, spacing->p0, spacing->p1, spacing->p2,
+                                                (double*)ctx->spacing_pp.p, (int32_t*)ctx->sp_hint.p);
+        if (rc) return rc;
+    }
     if ((rc = sync(ctx))) return rc;
     r.active = true;
     r.n = n;
@@ -453,6 +513,12 @@ static int relax_init_impl(wtp_ctx* ctx, const void* snap_xyz, bool on_device, i
     r.spacing_const = spacing->constant;
     r.spacing_max = spacing->constant;
     if (spacing->kind == WTP_SPACING_PER_POINT) r.spacing_max = host_max(spacing->per_point, n, dtype);
+    if (spacing_on_device(spacing->kind)) {
+        r.spacing_max = spacing_law_max(spacing);
+        r.sp_p0 = spacing->p0;
+        r.sp_p1 = spacing->p1;
+        r.sp_p2 = spacing->p2;
+    }
     r.alpha_lo = alpha_lo;
     r.alpha_max = alpha_max;
     r.force.kind = force->kind;
@@ -510,6 +576,16 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
         r.bufP = t;
         r.have_tree = true;
     }
+    if (spacing_on_device(r.spacing_kind)) {
+        // s = spacing(x_i) at the point's current position (src/repel.jl:251 on rebuilds, :260 in every
+        // sweep): the movable tail is re-evaluated before each sweep, the wall keeps its setup values
+        int sps = span_begin(ctx, 2);
+        rc = launch_spacing_session<T>(ctx, (const Pt<T>*)ctx->pts[r.bufP].p, r.n, r.n_fixed, ctx->kd_nodes.p, ctx->kd_m,
+                                       r.spacing_kind, r.sp_p0, r.sp_p1, r.sp_p2, (T*)ctx->spacing_pp.p,
+                                       (int32_t*)ctx->sp_hint.p);
+        span_end(ctx, sps);
+        if (rc) return rc;
+    }
     const bool fresh = (r.bufS == r.bufP);
     const int o = pick_free(r, r.bufS, r.bufP);
     if ((rc = ensure(ctx, ctx->pts[o], sizeof(Pt<T>) * (size_t)r.n))) return rc;
@@ -525,7 +601,7 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
     a.forces = (T*)ctx->forces.p;
     a.nn_dist = (T*)ctx->nn_dist.p;
     a.nn_id = (int32_t*)ctx->nn_id.p;
-    a.spacing_pp = r.spacing_kind == WTP_SPACING_PER_POINT ? (const T*)ctx->spacing_pp.p : nullptr;
+    a.spacing_pp = r.spacing_kind != WTP_SPACING_CONSTANT ? (const T*)ctx->spacing_pp.p : nullptr;
     a.spacing_const = (T)r.spacing_const;
     a.alpha_lo = (T)r.alpha_lo;
     a.alpha_max = (T)r.alpha_max;
@@ -728,6 +804,49 @@ WTP_API int wtp_relax_set_spacing(wtp_ctx* ctx, const void* spacing) {
     WTP_HIP(ctx, hipMemcpyAsync(ctx->spacing_pp.p, spacing, tsize(r.dtype) * (size_t)r.n, hipMemcpyHostToDevice,
                                 ctx->stream));
     r.spacing_max = host_max(spacing, r.n, r.dtype);
+    return sync(ctx);
+}
+
+WTP_API int wtp_relax_get_spacing(wtp_ctx* ctx, void* spacing_out) {
+    if (!ctx) return WTP_ERR_ARG;
+    RelaxState& r = ctx->relax;
+    if (!r.active) return fail(ctx, WTP_ERR_STATE, "wtp_relax_get_spacing before wtp_relax_init");
+    if (!spacing_out) return fail(ctx, WTP_ERR_ARG, "spacing_out is NULL");
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t ts = tsize(r.dtype);
+    if (r.spacing_kind == WTP_SPACING_CONSTANT) {
+        for (int64_t i = 0; i < r.n; ++i) {
+            if (r.dtype == WTP_F32) ((float*)spacing_out)[i] = (float)r.spacing_const;
+            else ((double*)spacing_out)[i] = r.spacing_const;
+        }
+        return WTP_OK;
+    }
+    WTP_HIP(ctx, hipMemcpyAsync(spacing_out, ctx->spacing_pp.p, ts * (size_t)r.n, hipMemcpyDeviceToHost, ctx->stream));
+    return sync(ctx);
+}
+
+WTP_API int wtp_spacing_eval(wtp_ctx* ctx, const wtp_spacing_desc* spacing, const void* xyz, int64_t n, int dim,
+                             int dtype, void* out) {
+    int rc = check_cloud(ctx, xyz, n, dim, dtype);
+    if (rc) return rc;
+    if (!spacing || !out) return fail(ctx, WTP_ERR_ARG, "spacing/out is NULL");
+    if (!spacing_on_device(spacing->kind))
+        return fail(ctx, WTP_ERR_ARG, "wtp_spacing_eval evaluates LOGLIKE / BOUNDARY_LAYER descriptors");
+    if ((rc = check_spacing_law(ctx, spacing))) return rc;
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t ts = tsize(dtype);
+    if ((rc = ensure_kd(ctx, spacing, dim, dtype))) return rc;
+    if ((rc = ensure(ctx, ctx->ins_in, ts * (size_t)n * dim))) return rc;
+    if ((rc = ensure(ctx, ctx->ins_out, ts * (size_t)n))) return rc;
+    WTP_HIP(ctx, hipMemcpyAsync(ctx->ins_in.p, xyz, ts * (size_t)n * dim, hipMemcpyHostToDevice, ctx->stream));
+    if (dtype == WTP_F32)
+        rc = launch_spacing_eval<float>(ctx, (const float*)ctx->ins_in.p, n, dim, ctx->kd_nodes.p, ctx->kd_m, spacing->kind,
+                                        spacing->p0, spacing->p1, spacing->p2, (float*)ctx->ins_out.p);
+    else
+        rc = launch_spacing_eval<double>(ctx, (const double*)ctx->ins_in.p, n, dim, ctx->kd_nodes.p, ctx->kd_m,
+                                         spacing->kind, spacing->p0, spacing->p1, spacing->p2, (double*)ctx->ins_out.p);
+    if (rc) return rc;
+    WTP_HIP(ctx, hipMemcpyAsync(out, ctx->ins_out.p, ts * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     return sync(ctx);
 }
 

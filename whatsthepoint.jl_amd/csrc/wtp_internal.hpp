@@ -140,6 +140,7 @@ struct RelaxState {
     double spacing_max = 0;  // largest spacing value (host-side max of the per-point array)
     int brick_hcap = 0;      // LDS point capacity of the sweep's brick kernel (0 = not chosen yet)
     bool cs_sweep = false;   // compact-support sweep in use (ClippedSpacingForce)
+    double sp_p0 = 0, sp_p1 = 0, sp_p2 = 0; // LOGLIKE / BOUNDARY_LAYER parameters
     int cover_axis = -1;     // sharded session: snapshot complete for cover_lo <= coord[axis] <= cover_hi
     double cover_lo = 0, cover_hi = 0;
 };
@@ -168,6 +169,11 @@ struct wtp_ctx {
     wtp::DevBuf scratch;       // misc (relax_get staging, radius rows)
     wtp::DevBuf diag;          // diagnostic builds only
     wtp::DevBuf ins_in, ins_elems, ins_partial, ins_out; // isinside filter
+    wtp::DevBuf sp_hint;       // variable spacings: nearest tree node of each snapshot point at the last sweep
+    wtp::DevBuf kd_nodes;      // variable spacings: kd-tree over the boundary points (heap order)
+    int64_t kd_m = 0;          // nodes in it; the key below identifies the boundary it was built from
+    uint64_t kd_key = 0;
+    int kd_dim = 0, kd_dtype = -1;
     void* host_pinned = nullptr;
     size_t host_pinned_cap = 0;
     // radius two-phase state
@@ -243,6 +249,15 @@ template <typename T>
 int launch_set_point(wtp_ctx* ctx, Pt<T>* pts, int64_t n, int32_t id, int dim, const T* d_xyz3);
 template <typename T>
 int launch_gen_uniform(wtp_ctx* ctx, uint64_t seed, int64_t first, int64_t n, int dim, T* d_out);
+// variable spacing laws on the device (wtp_spacing.hip)
+template <typename T> size_t kd_bytes(int64_t m);
+template <typename T> void kd_build_host(const T* xyz, int64_t m, int dim, void* out);
+template <typename T>
+int launch_spacing_eval(wtp_ctx* ctx, const T* d_xyz, int64_t n, int dim, const void* d_nodes, int64_t m, int kind,
+                        double p0, double p1, double p2, T* d_out);
+template <typename T>
+int launch_spacing_session(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int64_t first_id, const void* d_nodes, int64_t m,
+                           int kind, double p0, double p1, double p2, T* d_spacing_pp, int32_t* d_hint);
 // isinside post-filter (wtp_inside.hip)
 int isinside_chunks(wtp_ctx* ctx, int64_t n, int64_t m, int points_per_block);
 int isinside_greens_ppb();

@@ -1,0 +1,271 @@
+// wtp_spacing.hip — the variable spacing laws evaluated on the device.
+//
+//   LogLike               h0 x / (a + x),  a = h0 (1 - (g - 1))          src/discretization/spacings.jl:67-72
+//   BoundaryLayerSpacing  h_w + (h_b - h_w) / (1 + exp(-(d - δ/2)/(δ/6)))    :121-133
+// with x = d = distance to the nearest boundary point (_min_distance, :17-22: a 1-NN query of a
+// kd-tree over the boundary points).  The sweep calls the law at every movable point every
+// iteration (src/repel.jl:251,260), so the query has to live next to the sweep.
+//
+// Search structure: the boundary is static for a whole repel call, so it gets a left-balanced
+// kd-tree built once on the host (median split on the widest axis, heap order: children of node
+// i are 2i+1 and 2i+2, one boundary point per node, no pointers; every node also stores the
+// bounding box of its subtree).  A uniform grid would not do: boundary points lie on a surface and
+// a query deep inside the domain would have to walk O((d/c)^3) empty cells.  Device traversal:
+// depth-first, near child first, far child pushed; a popped subtree is skipped when the distance
+// from the query to its box cannot beat the best so far.  (The split-plane distance alone is far
+// too weak a bound here: a query 0.3 away from a wall sampled every 0.005 is within 0.3 of
+// thousands of split planes — measured 100 ms per million queries, against 0.7 ms with boxes.)
+// Exact: the value returned is min over canonical d2 = ((dx*dx + dy*dy) + dz*dz), the same number
+// a brute-force scan gives — the box bound is monotone under rounding (each of its terms is <= the
+// matching term of any point inside the box, and rounded sums are monotone in their arguments).
+// Cell-sorted queries make neighbouring lanes walk nearly the same path.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "wtp_device.hpp"
+
+namespace wtp {
+
+static constexpr int kSpThreads = 256;
+
+// nodes in the left subtree of a left-balanced binary tree with n nodes
+static int64_t kd_left_size(int64_t n) {
+    if (n <= 1) return 0;
+    int h = 0;
+    while ((int64_t(1) << (h + 1)) <= n) ++h; // h = floor(log2 n): levels 0..h-1 are full
+    const int64_t full = (int64_t(1) << h) - 1;
+    const int64_t last = n - full;
+    const int64_t half = int64_t(1) << (h - 1);
+    return (full - 1) / 2 + (last < half ? last : half);
+}
+
+template <typename T> struct HostPt { T c[3]; };
+
+template <typename T> struct KdBox { T lo[3], hi[3]; };
+// One record per node, fetched with a single (wave-uniform) load per traversal step: the point with
+// its split axis in w, and the box of the subtree below it.  48 B (fp32) / 96 B (fp64).
+template <typename T> struct KdNode {
+    Pt<T> p;
+    KdBox<T> box;
+    T pad[2];
+};
+
+template <typename T>
+static void kd_build_rec(std::vector<HostPt<T>>& pts, int64_t lo, int64_t hi, int64_t node, int dim, KdNode<T>* out) {
+    while (hi > lo) {
+        const int64_t n = hi - lo;
+        T mn[3], mx[3];
+        for (int a = 0; a < 3; ++a) mn[a] = mx[a] = pts[lo].c[a];
+        for (int64_t i = lo + 1; i < hi; ++i)
+            for (int a = 0; a < dim; ++a) {
+                mn[a] = pts[i].c[a] < mn[a] ? pts[i].c[a] : mn[a];
+                mx[a] = pts[i].c[a] > mx[a] ? pts[i].c[a] : mx[a];
+            }
+        for (int a = 0; a < 3; ++a) {
+            out[node].box.lo[a] = mn[a];
+            out[node].box.hi[a] = mx[a];
+        }
+        out[node].pad[0] = out[node].pad[1] = (T)0;
+        int sd = 0;
+        for (int a = 1; a < dim; ++a)
+            if (mx[a] - mn[a] > mx[sd] - mn[sd]) sd = a;
+        const int64_t L = kd_left_size(n);
+        std::nth_element(pts.begin() + lo, pts.begin() + lo + L, pts.begin() + hi,
+                         [sd](const HostPt<T>& a, const HostPt<T>& b) { return a.c[sd] < b.c[sd]; });
+        const HostPt<T>& m = pts[lo + L];
+        Pt<T> o;
+        o.x = m.c[0];
+        o.y = m.c[1];
+        o.z = m.c[2];
+        o.w = id_to_w((T)0, (int32_t)sd);
+        out[node].p = o;
+        kd_build_rec<T>(pts, lo, lo + L, 2 * node + 1, dim, out); // left: recursion depth = tree height
+        lo = lo + L + 1;                                            // right: iterate
+        node = 2 * node + 2;
+    }
+}
+
+// Host build into `out`: m node records in heap order.
+template <typename T> size_t kd_bytes(int64_t m) { return sizeof(KdNode<T>) * (size_t)m; }
+
+template <typename T> void kd_build_host(const T* xyz, int64_t m, int dim, void* out_raw) {
+    KdNode<T>* out = (KdNode<T>*)out_raw;
+    std::vector<HostPt<T>> pts((size_t)m);
+    for (int64_t i = 0; i < m; ++i) {
+        pts[i].c[0] = xyz[i * dim];
+        pts[i].c[1] = xyz[i * dim + 1];
+        pts[i].c[2] = dim == 3 ? xyz[i * dim + 2] : (T)0;
+    }
+    kd_build_rec<T>(pts, 0, m, 0, dim, out);
+}
+
+template <typename T>
+__device__ inline T box_d2(const KdBox<T>& b, T qx, T qy, T qz) {
+    const T q[3] = {qx, qy, qz};
+    T t[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const T below = b.lo[a] - q[a], above = q[a] - b.hi[a];
+        const T m = below > above ? below : above;
+        t[a] = m > (T)0 ? m : (T)0;
+    }
+    return (t[0] * t[0] + t[1] * t[1]) + t[2] * t[2];
+}
+
+// Packet traversal: the 64 queries of a wave walk the tree TOGETHER.  `node` and the stack are
+// wave-uniform (the stack is a 64-entry LDS row per wave), so every node and box is fetched once
+// per wave through uniform loads
+// instead of 64 divergent ones, and there is no lane divergence at all.  A subtree is entered
+// when its box can still improve SOME lane's best; each lane keeps its own best over the canonical
+// d2, so visiting extra nodes never changes a result.  For cell-sorted queries (session order) a
+// wave's queries sit within a few cells of each other and the union of their search paths is
+// hardly longer than one path.
+// hint: a node believed to be near the query (its nearest node of the previous sweep) or -1; it
+// only seeds `best`.  *best_node: the minimiser.  Inactive lanes (tail of the grid) never want a
+// subtree.  Measured at 8 M queries x 46 786 boundary points: per-lane traversal (64 divergent
+// walks per wave) 3.3 ms, packet traversal 1.0 ms.
+template <typename T>
+__device__ inline T kd_nearest_d2(const KdNode<T>* __restrict__ nodes, int32_t m, T qx, T qy, T qz, bool active,
+                                  int32_t hint, int32_t* best_node, int32_t* __restrict__ stack /* LDS, this wave's */) {
+    T best = active ? Lim<T>::inf() : (T)-1; // box_d2 >= 0 > -1: an inactive lane never asks for anything
+    int32_t bn = -1;
+    if (active && hint >= 0 && hint < m) {
+        const Pt<T> p = nodes[hint].p;
+        best = dist2<T>(qx, qy, qz, p.x, p.y, p.z);
+        bn = hint;
+    }
+    int sp = 0;        // uniform
+    int32_t node = 0;  // uniform
+    for (;;) {
+        node = __builtin_amdgcn_readfirstlane(node);
+        const KdNode<T> nd = nodes[node]; // one uniform fetch per step
+        const bool want = box_d2<T>(nd.box, qx, qy, qz) < best;
+        bool descended = false;
+        if (__any(want)) {
+            const Pt<T> p = nd.p;
+            const T d2 = dist2<T>(qx, qy, qz, p.x, p.y, p.z);
+            const bool better = active && d2 < best;
+            bn = better ? node : bn;
+            best = better ? d2 : best;
+            const int32_t sd = w_to_id(p.w);
+            const T diff = sd == 0 ? qx - p.x : (sd == 1 ? qy - p.y : qz - p.z);
+            const int32_t left = 2 * node + 1;
+            // the side most of the interested lanes lie on goes first
+            const int nl = __popcll(__ballot(want && diff < (T)0)), nr = __popcll(__ballot(want && !(diff < (T)0)));
+            const int32_t first = left + (nl >= nr ? 0 : 1), second = left + (nl >= nr ? 1 : 0);
+            if (second < m && sp < 64) { // one push per level at most: 2^31 points have 31 levels
+                if ((threadIdx.x & 63) == 0) stack[sp] = second;
+                ++sp;
+            }
+            if (first < m) {
+                node = first;
+                descended = true;
+            }
+        }
+        if (!descended) {
+            if (sp == 0) break;
+            node = stack[--sp];
+        }
+    }
+    *best_node = bn;
+    return best;
+}
+
+template <typename T> struct SpacingLaw {
+    int32_t kind; // WTP_SPACING_LOGLIKE / WTP_SPACING_BOUNDARY_LAYER
+    T p0, p1, p2;
+};
+
+__device__ inline float wexp(float x) { return expf(x); }
+__device__ inline double wexp(double x) { return exp(x); }
+
+template <typename T> __device__ inline T spacing_law(const SpacingLaw<T>& law, T d) {
+    if (law.kind == WTP_SPACING_LOGLIKE) { // base_size * x / (a + x), a = base_size * (1 - (growth_rate - 1))
+        const T inv_growth = (T)1 - (law.p1 - (T)1);
+        const T a = law.p0 * inv_growth;
+        return law.p0 * d / (a + d);
+    }
+    const T center = law.p2 / (T)2, width = law.p2 / (T)6; // at_wall + (bulk - at_wall) * sigma
+    const T sig = (T)1 / ((T)1 + wexp(-(d - center) / width));
+    return law.p0 + (law.p1 - law.p0) * sig;
+}
+
+// Raw AoS points -> spacing values (wtp_spacing_eval).
+template <typename T>
+__global__ void spacing_eval_kernel(const T* __restrict__ xyz, int64_t n, int dim, const KdNode<T>* __restrict__ nodes,
+                                    int32_t m, SpacingLaw<T> law, T* __restrict__ out) {
+    __shared__ int32_t kd_stack[kSpThreads / 64][64];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t span = (n + 63) / 64 * 64; // whole waves walk the tree together
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < span; i += stride) {
+        const bool active = i < n;
+        const int64_t ii = active ? i : n - 1;
+        const T x = xyz[ii * dim], y = xyz[ii * dim + 1], z = dim == 3 ? xyz[ii * dim + 2] : (T)0;
+        int32_t bn;
+        const T d2 = kd_nearest_d2<T>(nodes, m, x, y, z, active, -1, &bn, kd_stack[threadIdx.x >> 6]);
+        if (active) out[i] = spacing_law<T>(law, wsqrt(d2));
+    }
+}
+
+// Session points (slot order, id in w) -> spacing_pp[id]; ids below first_id keep their value.
+template <typename T>
+__global__ void spacing_session_kernel(const Pt<T>* __restrict__ pts, int64_t n, int32_t first_id,
+                                       const KdNode<T>* __restrict__ nodes, int32_t m, SpacingLaw<T> law,
+                                       T* __restrict__ spacing_pp, int32_t* __restrict__ hint) {
+    __shared__ int32_t kd_stack[kSpThreads / 64][64];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t span = (n + 63) / 64 * 64; // whole waves walk the tree together
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < span; i += stride) {
+        const Pt<T> p = pts[i < n ? i : n - 1];
+        const int32_t id = w_to_id(p.w);
+        const bool active = i < n && id >= first_id;
+        if (!__any(active)) continue;
+        int32_t bn;
+        const T d2 = kd_nearest_d2<T>(nodes, m, p.x, p.y, p.z, active, active ? hint[id] : -1, &bn,
+                                      kd_stack[threadIdx.x >> 6]);
+        if (active) {
+            spacing_pp[id] = spacing_law<T>(law, wsqrt(d2));
+            hint[id] = bn; // points move a fraction of a spacing per sweep: next time this is (nearly) the answer
+        }
+    }
+}
+
+static int sp_grid(int64_t n) {
+    int64_t b = (n + kSpThreads - 1) / kSpThreads;
+    return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
+template <typename T>
+int launch_spacing_eval(wtp_ctx* ctx, const T* d_xyz, int64_t n, int dim, const void* d_nodes, int64_t m, int kind,
+                        double p0, double p1, double p2, T* d_out) {
+    SpacingLaw<T> law{kind, (T)p0, (T)p1, (T)p2};
+    hipLaunchKernelGGL(spacing_eval_kernel<T>, dim3(sp_grid(n)), dim3(kSpThreads), 0, ctx->stream, d_xyz, n, dim,
+                       (const KdNode<T>*)d_nodes, (int32_t)m, law, d_out);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
+template <typename T>
+int launch_spacing_session(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int64_t first_id, const void* d_nodes, int64_t m,
+                           int kind, double p0, double p1, double p2, T* d_spacing_pp, int32_t* d_hint) {
+    SpacingLaw<T> law{kind, (T)p0, (T)p1, (T)p2};
+    hipLaunchKernelGGL(spacing_session_kernel<T>, dim3(sp_grid(n)), dim3(kSpThreads), 0, ctx->stream, pts, n,
+                       (int32_t)first_id, (const KdNode<T>*)d_nodes, (int32_t)m, law, d_spacing_pp, d_hint);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
+#define INST(T)                                                                                              \
+    template size_t kd_bytes<T>(int64_t);                                                                    \
+    template void kd_build_host<T>(const T*, int64_t, int, void*);                                           \
+    template int launch_spacing_eval<T>(wtp_ctx*, const T*, int64_t, int, const void*, int64_t, int, double, \
+                                        double, double, T*);                                                 \
+    template int launch_spacing_session<T>(wtp_ctx*, const Pt<T>*, int64_t, int64_t, const void*, int64_t, int, \
+                                           double, double, double, T*, int32_t*);
+INST(float)
+INST(double)
+#undef INST
+
+} // namespace wtp

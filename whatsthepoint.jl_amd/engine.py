@@ -103,6 +103,17 @@ class Context:
     def relax(self, snap, n_fixed: int, spacing, force, k: int, alpha_lo: float, alpha_max: float, device_ptr=None):
         return RelaxSession(self, snap, n_fixed, spacing, force, k, alpha_lo, alpha_max, device_ptr=device_ptr)
 
+    # ---- variable spacing laws at arbitrary points (spacing.(points)) ---------------------------
+    def spacing_eval(self, law: dict, xyz):
+        xyz = _cloud(xyz)
+        sd, keep = _law_desc(law, xyz.dtype, xyz.shape[1])
+        out = np.empty(len(xyz), dtype=xyz.dtype)
+        rc = self._lib.wtp_spacing_eval(self._h, C.byref(sd), _vp(xyz), len(xyz), xyz.shape[1], _dtype_code(xyz.dtype),
+                                        _vp(out))
+        L.check(self._h, rc)
+        del keep
+        return out
+
     # ---- isinside post-filter (src/repel.jl:90; src/isinside.jl) -------------------------------
     def isinside_greens(self, test, elem_xyz, elem_normal, elem_area, return_g: bool = False):
         """3-D: bool[n] (and g[n]) for test points against boundary elements (centroid, normal, area)."""
@@ -159,6 +170,19 @@ class Context:
         L.check(self._h, rc)
 
 
+def _law_desc(law: dict, dtype, dim: int):
+    """wtp_spacing_desc for a device-evaluated law: dict(kind=2|3, p0, p1, p2, boundary=(m, dim) array).
+    Returns (desc, keepalive)."""
+    b = np.ascontiguousarray(law["boundary"], dtype=dtype)
+    if b.ndim != 2 or b.shape[1] != dim:
+        raise L.WtpArgumentError(f"the spacing law's boundary points must be (m, {dim})")
+    sd = L.SpacingDesc()
+    sd.kind, sd.constant, sd.per_point = int(law["kind"]), 0.0, None
+    sd.p0, sd.p1, sd.p2 = float(law["p0"]), float(law["p1"]), float(law.get("p2", 0.0))
+    sd.boundary_xyz, sd.n_boundary = b.ctypes.data, len(b)
+    return sd, b
+
+
 def _stats_dict(s: L.StepStats):
     return dict(max_force=s.max_force, sum_u=s.sum_u, sum_u2=s.sum_u2, n_move=s.n_move, argmin_i=s.argmin_i,
                 argmin_j=s.argmin_j, argmin_r=s.argmin_r, n_fallback=s.n_fallback, n_uncovered=s.n_uncovered)
@@ -186,6 +210,8 @@ class RelaxSession:
         self._sp_keep = None
         if np.isscalar(spacing):
             sd.kind, sd.constant, sd.per_point = 0, float(spacing), None
+        elif isinstance(spacing, dict):  # a law the library evaluates itself (LogLike / BoundaryLayerSpacing)
+            sd, self._sp_keep = _law_desc(spacing, self.dtype, self.dim)
         else:
             sp = np.ascontiguousarray(spacing, dtype=self.dtype)
             if sp.shape != (self.n,):
@@ -243,6 +269,12 @@ class RelaxSession:
 
     def revert(self):
         L.check(self.ctx._h, self._lib.wtp_relax_revert(self.ctx._h))
+
+    def spacings(self):
+        """The per-point spacings the session holds, snapshot order (src/repel.jl:209,251)."""
+        out = np.empty(self.n, dtype=self.dtype)
+        L.check(self.ctx._h, self._lib.wtp_relax_get_spacing(self.ctx._h, _vp(out)))
+        return out
 
     def set_spacing(self, spacing):
         sp = np.ascontiguousarray(spacing, dtype=self.dtype)

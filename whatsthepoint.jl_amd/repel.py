@@ -50,16 +50,21 @@ def relax(p, snap_fixed, spacing, force_model, *, alpha_lo, alpha_max, k=21, max
     snap = np.concatenate([np.asarray(snap_fixed, dtype=p.dtype).reshape(n_fixed, p.shape[1]), p], axis=0)
     n_move = len(p)
     n_protected = n_fixed if n_protected is None else n_protected
-    sp, const = _spacing_values(spacing, snap)
-    spacings = np.full(len(snap), sp, dtype=p.dtype) if const else sp
-    variable = (not const) and callable(spacing)
+    on_device = hasattr(spacing, "desc")   # LogLike / BoundaryLayerSpacing: the library evaluates the law
+    if on_device:
+        sp, const, spacings = None, False, None
+    else:
+        sp, const = _spacing_values(spacing, snap)
+        spacings = np.full(len(snap), sp, dtype=p.dtype) if const else sp
+    variable = (not const) and callable(spacing) and not on_device
     conv = []
     if n_move == 0 or max_iters < 1:
         return p, conv
     rng = rng or np.random.default_rng()
     kick_state = dict(pair=(0, 0), rs=math.inf, count=0)
     best_cv, last_impr = math.inf, 0
-    sess = ctx.relax(snap, n_fixed, sp if const else spacings, force_model.desc(), k, alpha_lo, alpha_max)
+    sess = ctx.relax(snap, n_fixed, spacing.desc() if on_device else (sp if const else spacings), force_model.desc(),
+                     k, alpha_lo, alpha_max)
     try:
         i = 1
         while i <= max_iters:
@@ -72,6 +77,8 @@ def relax(p, snap_fixed, spacing, force_model, *, alpha_lo, alpha_max, k=21, max
             st = sess.step(rebuild)
             conv.append(st["max_force"])  # maximum(forces) :293
             if n_move > 0 and (trace is not None or kick_after > 0):
+                if on_device:
+                    spacings = sess.spacings()  # the values this sweep used (src/repel.jl:251)
                 ig, j, r = st["argmin_i"], st["argmin_j"], st["argmin_r"]  # _closest_pair :396-403
                 s_pair = (spacings[ig] + spacings[j]) / 2 if j >= 0 else spacings[ig]
                 pair = dict(r=r, s=float(s_pair), r_over_s=r / float(s_pair), idx_a=min(ig, j), idx_b=max(ig, j))

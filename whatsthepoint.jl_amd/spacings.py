@@ -1,7 +1,9 @@
-"""Spacing callables (src/discretization/spacings.jl).  Inside the sweep the device uses a
-constant or a per-point array (include/wtp.h wtp_spacing_desc); the variable laws are evaluated
-on the host against the boundary points and handed over as that array (their device-side
-evaluation is SURVEY.md §8f item 3)."""
+"""Spacing callables (src/discretization/spacings.jl).  `ConstantSpacing` is a scalar inside the
+sweep; `LogLike` and `BoundaryLayerSpacing` are evaluated by the library on the GPU — inside the
+sweep at every point's current position (include/wtp.h wtp_spacing_desc kinds 2 and 3) and, when
+called on points here, through wtp_spacing_eval: the distance to the nearest boundary point is a
+kd-tree 1-NN query on the device (csrc/wtp_spacing.hip).  Any other callable is evaluated by the
+caller on the host and handed over as a per-point array."""
 from __future__ import annotations
 
 import numpy as np
@@ -23,11 +25,13 @@ class ConstantSpacing(AbstractSpacing):  # spacings.jl:35-39
         return self.dx if pts.ndim == 1 else np.full(len(pts), self.dx, dtype=pts.dtype)
 
 
-def _min_distance(pts, boundary):  # spacings.jl:19-23 (1-NN to the boundary points)
-    from scipy.spatial import cKDTree
+def _eval(law, pts, ctx=None):
+    from .engine import default_context
 
-    d, _ = cKDTree(np.asarray(boundary, dtype=np.float64)).query(np.asarray(pts, dtype=np.float64), k=1)
-    return d
+    pts = np.asarray(pts)
+    single = pts.ndim == 1
+    out = (ctx or default_context()).spacing_eval(law.desc(), np.atleast_2d(pts))
+    return out[0] if single else out
 
 
 class LogLike(AbstractSpacing):  # spacings.jl:49-72
@@ -37,11 +41,11 @@ class LogLike(AbstractSpacing):  # spacings.jl:49-72
         self.boundary = np.asarray(boundary_points)
         self.base_size, self.growth_rate = float(base_size), float(growth_rate)
 
-    def __call__(self, pts):
-        pts = np.atleast_2d(pts)
-        x = _min_distance(pts, self.boundary)
-        a = self.base_size * (1 - (self.growth_rate - 1))
-        return (self.base_size * x / (a + x)).astype(pts.dtype)
+    def desc(self):
+        return dict(kind=2, p0=self.base_size, p1=self.growth_rate, p2=0.0, boundary=self.boundary)
+
+    def __call__(self, pts, ctx=None):
+        return _eval(self, pts, ctx)
 
 
 class BoundaryLayerSpacing(AbstractSpacing):  # spacings.jl:93-133
@@ -53,9 +57,8 @@ class BoundaryLayerSpacing(AbstractSpacing):  # spacings.jl:93-133
         self.boundary = np.asarray(boundary_points)
         self.at_wall, self.bulk, self.layer_thickness = float(at_wall), float(bulk), float(layer_thickness)
 
-    def __call__(self, pts):
-        pts = np.atleast_2d(pts)
-        d = _min_distance(pts, self.boundary)
-        center, width = self.layer_thickness / 2, self.layer_thickness / 6
-        sig = 1.0 / (1.0 + np.exp(-(d - center) / width))
-        return (self.at_wall + (self.bulk - self.at_wall) * sig).astype(pts.dtype)
+    def desc(self):
+        return dict(kind=3, p0=self.at_wall, p1=self.bulk, p2=self.layer_thickness, boundary=self.boundary)
+
+    def __call__(self, pts, ctx=None):
+        return _eval(self, pts, ctx)
