@@ -45,6 +45,69 @@ def cpu_baseline(points: int, iters: int):
                 sample=f"{iters} repel iterations on {points} uniform fp32 points (kd-tree + OpenMP oracle, {dt:.1f} s)")
 
 
+def other_paths(ctx, torch, np, wtp_amd):
+    """Secondary lines of SURVEY.md §8d, measured in the same run on the same GPU (N=1 only):
+    KNNTopology k=21 at 1 M points (C2), RadiusTopology on 1 M points at a radius holding ~21
+    neighbours, and the isinside filter of repel's tail.  Device-resident where the ABI allows."""
+    out = {}
+    n, k = 1_000_000, 21
+    x = torch.empty((n, 3), dtype=torch.float32, device="cuda")
+    ctx.gen_uniform_dev(wtp_amd.synth.SEED, 0, n, 3, np.float32, x.data_ptr())
+    idx = torch.empty((n, k), dtype=torch.int32, device="cuda")
+    for _ in range(2):
+        ctx.knn_dev(x.data_ptr(), n, 3, np.float32, k, False, idx.data_ptr())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        ctx.knn_dev(x.data_ptr(), n, 3, np.float32, k, False, idx.data_ptr())
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    out["knn_topology_k21_1M"] = {"value": round(n / dt / 1e6, 1), "unit": "Mpoints/s", "ms": round(dt * 1e3, 3),
+                                  "alg_gbs": round(151.0 * n / dt / 1e9, 1),
+                                  "note": "wtp_knn_dev: hash + brick_kernel<0,21,0>, rows int32 on device"}
+    xh = x.cpu().numpy()
+    del x, idx
+    r = (21.0 / (4.0 / 3.0 * np.pi * n)) ** (1.0 / 3.0)
+    ctx.radius(xh[:100000], r)
+    t0 = time.perf_counter()
+    off, ridx = ctx.radius(xh, r)
+    dt = time.perf_counter() - t0
+    out["radius_topology_1M"] = {"value": round(n / dt / 1e6, 1), "unit": "Mpoints/s", "ms": round(dt * 1e3, 2),
+                                 "pairs": int(off[-1]), "note": "wtp_radius_count + fill, host arrays in and out "
+                                 "(PCIe and the host-side offsets scan included)"}
+    # isinside: m = 46 786 elements like the reference's box.stl, synthetic (a cube's faces) so that no file is needed
+    m_side = 88
+    g = (np.arange(m_side, dtype=np.float32) + 0.5) / m_side
+    u, v = np.meshgrid(g, g, indexing="ij")
+    faces, normals = [], []
+    for axis in range(3):
+        for side in (0.0, 1.0):
+            c = np.zeros((m_side * m_side, 3), np.float32)
+            c[:, axis] = side
+            c[:, (axis + 1) % 3] = u.ravel()
+            c[:, (axis + 2) % 3] = v.ravel()
+            nn = np.zeros_like(c)
+            nn[:, axis] = 1.0 if side else -1.0
+            faces.append(c)
+            normals.append(nn)
+    ec, en = np.concatenate(faces), np.concatenate(normals)
+    ea = np.full(len(ec), 1.0 / (m_side * m_side), np.float32)
+    t = (wtp_amd.synth.uniform(2_000_000, 3, np.float32, 3) * 1.2 - 0.1).astype(np.float32)
+    ctx.isinside_greens(t[:1000], ec, en, ea)
+    ctx.timers_reset()
+    t0 = time.perf_counter()
+    ins = ctx.isinside_greens(t, ec, en, ea)
+    dt = time.perf_counter() - t0
+    dev = ctx.timers()["other_ms"] * 1e-3
+    out["isinside_greens_2M_x_46k"] = {"value": round(len(t) / dt / 1e6, 2), "unit": "Mpoints/s", "ms": round(dt * 1e3, 2),
+                                       "kernel_ms": round(dev * 1e3, 2),
+                                       "tera_pairs_per_s": round(len(t) * len(ec) / dev / 1e12, 3),
+                                       "inside_fraction": round(float(ins.mean()), 4),
+                                       "note": "wtp_isinside_greens, host arrays in and out; VALU-bound (13 instr/pair)"}
+    return out
+
+
 def ctx_rho() -> float:
     try:
         return float(os.environ.get("WTP_RHO", "8"))
@@ -60,6 +123,7 @@ def main():
     ap.add_argument("--points", type=int, default=10_000_000, help="points per GPU (weak scaling)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-full-select", action="store_true", help="skip the explicit k-selection leg")
+    ap.add_argument("--no-other-paths", action="store_true", help="skip the k-NN / radius / isinside lines")
     ap.add_argument("--cpu-points", type=int, default=4_000_000)
     ap.add_argument("--cpu-iters", type=int, default=6)
     args = ap.parse_args()
@@ -142,8 +206,10 @@ def main():
     # runs the 64-key network), N=1 only: the default path above certifies by counting that the
     # k-list is not needed for ClippedSpacingForce; both produce the same step.
     full_sel = None
+    sess_closed = False
     if world == 1 and not args.no_full_select:
         sess.close()
+        sess_closed = True
         os.environ["WTP_FULL_SELECT"] = "1"
         try:
             ctx2 = wtp_amd.Context(local_rank)
@@ -225,6 +291,10 @@ def main():
             out["roofline"]["algorithmic_bytes"] = round(B_ALG_SWEEP * pts_per_launch)
         if full_sel is not None:
             out["full_k_selection_path"] = full_sel
+        if world == 1 and not args.no_other_paths:
+            if not sess_closed:
+                sess.close()
+            out["other_paths"] = other_paths(ctx, torch, np, wtp_amd)
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.cpu_points, args.cpu_iters)
         print(json.dumps(out), flush=True)
