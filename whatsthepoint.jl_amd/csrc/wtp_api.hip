@@ -124,6 +124,57 @@ static int check_cloud(wtp_ctx* ctx, const void* xyz, int64_t n, int dim, int dt
     return WTP_OK;
 }
 
+// ---- hash with a measured cell edge ------------------------------------------------------------------
+// build_hash sizes its cells from the box average n / volume.  That is right for a cloud that fills
+// its box evenly and wrong for graded clouds (a 64x density contrast puts ~85 points into every wall
+// cell), for surface clouds and for boxes stretched by a few outliers: the occupied cells then hold
+// far more points than intended, halos overflow the LDS and whole bricks drop to the slow exact
+// path (measured: 157 ms instead of ~2 ms per iteration on a 1 M-point graded cloud).  So the
+// first build of a session / call measures the occupancy the POINTS see (sum cnt^2 / sum cnt, = rho + 1
+// for a Poisson cloud) and shrinks the cell edge until that matches the target; at most 3 builds,
+// one small read-back each.  Floors (radius, the force law's support) stay in force.
+static double hash_target_rho(const wtp_ctx* ctx, int dim, int k, double radius, double rho_direct) {
+    if (radius > 0) return 2.0;
+    if (rho_direct > 0) return rho_direct < 1.0 ? 1.0 : rho_direct;
+    const double r = (dim == 3 ? 0.381 : 0.436) * (double)(k > 0 ? k : 21) * (ctx->rho / 8.0);
+    return r < 1.0 ? 1.0 : r;
+}
+
+template <typename T>
+static int build_hash_tuned(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, int k, double radius,
+                            double rho_direct, double min_cell, double* scale_io, double* rho_eff_out, Grid<T>* hg_out) {
+    const double target = hash_target_rho(ctx, dim, k, radius, rho_direct);
+    double scale = *scale_io > 0 ? *scale_io : 1.0;
+    double prev_c = -1;
+    int rc;
+    if ((rc = ensure(ctx, ctx->occ, 64))) return rc;
+    if ((rc = ensure_pinned(ctx, 1024))) return rc;
+    for (int round = 0; round < 3; ++round) {
+        if ((rc = build_hash<T>(ctx, in, out, n, dim, k, radius, rho_direct, min_cell, scale))) return rc;
+        if ((rc = launch_occupancy(ctx, (unsigned long long*)ctx->occ.p))) return rc;
+        char* hp = (char*)ctx->host_pinned;
+        WTP_HIP(ctx, hipMemcpyAsync(hp, ctx->occ.p, 24, hipMemcpyDeviceToHost, ctx->stream));
+        WTP_HIP(ctx, hipMemcpyAsync(hp + 64, ctx->grid.p, sizeof(Grid<T>), hipMemcpyDeviceToHost, ctx->stream));
+        if ((rc = sync(ctx))) return rc;
+        const unsigned long long* o = (const unsigned long long*)hp;
+        const double rho_eff = o[1] ? (double)o[0] / (double)o[1] : 1.0;
+        Grid<T> hg;
+        memcpy(&hg, hp + 64, sizeof(hg));
+        *rho_eff_out = rho_eff;
+        *hg_out = hg;
+        const double excess = (rho_eff - 1.0) / target;
+        if (!(excess > 1.6) || round == 2) break;
+        if (prev_c > 0 && !((double)hg.c < prev_c * 0.999)) break; // a floor binds: shrinking changes nothing
+        prev_c = (double)hg.c;
+        double f = std::cbrt(1.15 / excess); // occupancy ~ c^3 (c^2 on surfaces: the next round catches up)
+        if (f < 0.3) f = 0.3;
+        scale *= f;
+        if (scale < 0.02) scale = 0.02;
+    }
+    *scale_io = scale;
+    return WTP_OK;
+}
+
 // ---- topology -----------------------------------------------------------------------------------
 template <typename T>
 static int knn_dev_t(wtp_ctx* ctx, const T* d_xyz, int64_t n, int dim, int k, int include_self,
@@ -140,7 +191,20 @@ static int knn_dev_t(wtp_ctx* ctx, const T* d_xyz, int64_t n, int dim, int k, in
     int sp = span_begin(ctx, 0);
     if ((rc = load_points<T>(ctx, d_xyz, raw, n, dim))) return rc;
     // neighbours sought per query inside the structure: k others + self
-    if ((rc = build_hash<T>(ctx, raw, sorted, n, dim, include_self ? k : k + 1, 0.0))) return rc;
+    // The measured cell scale of the last topology call is reused for a cloud of the same size (the
+    // usual case: rebuild_topology! on the same points); it only affects speed, never the result.
+    const int kq = include_self ? k : k + 1;
+    if (ctx->knn_tune_n == n && ctx->knn_tune_dim == dim && ctx->knn_tune_k == kq) {
+        if ((rc = build_hash<T>(ctx, raw, sorted, n, dim, kq, 0.0, 0.0, 0.0, ctx->knn_tune_scale))) return rc;
+    } else {
+        double scale = 1.0, rho_eff = 0;
+        Grid<T> hg;
+        if ((rc = build_hash_tuned<T>(ctx, raw, sorted, n, dim, kq, 0.0, 0.0, 0.0, &scale, &rho_eff, &hg))) return rc;
+        ctx->knn_tune_n = n;
+        ctx->knn_tune_dim = dim;
+        ctx->knn_tune_k = kq;
+        ctx->knn_tune_scale = scale;
+    }
     span_end(ctx, sp);
     SearchArgs<T> a{};
     a.grid = (const Grid<T>*)ctx->grid.p;
@@ -221,6 +285,7 @@ WTP_API int wtp_create(const int* device_ordinals, int n_dev, wtp_ctx** out) {
     if (const char* e = getenv("WTP_GAMMA_CAP")) ctx->gamma_cap = atof(e) > 0 ? atof(e) : ctx->gamma_cap;
     if (const char* e = getenv("WTP_FORCE_GENERIC")) ctx->force_generic = atoi(e);
     if (const char* e = getenv("WTP_FULL_SELECT")) ctx->full_select = atoi(e);
+    if (const char* e = getenv("WTP_STYP_SIGMA")) ctx->styp_sigma = atof(e);
     if (const char* e = getenv("WTP_TIMING")) ctx->timing = atoi(e) != 0;
     *out = ctx;
     return WTP_OK;
@@ -235,7 +300,7 @@ WTP_API int wtp_destroy(wtp_ctx* ctx) {
                       &ctx->idx_out, &ctx->dist_out, &ctx->counts_out, &ctx->forces, &ctx->nn_dist,
                       &ctx->nn_id, &ctx->spacing_pp, &ctx->partials, &ctx->stats, &ctx->fb_list,
                       &ctx->fb_count, &ctx->fb2_list, &ctx->fb2_count, &ctx->scratch, &ctx->diag,
-                      &ctx->ins_in, &ctx->ins_elems, &ctx->ins_partial, &ctx->ins_out, &ctx->kd_nodes, &ctx->sp_hint};
+                      &ctx->ins_in, &ctx->ins_elems, &ctx->ins_partial, &ctx->ins_out, &ctx->kd_nodes, &ctx->sp_hint, &ctx->occ};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     if (ctx->host_pinned) hipHostFree(ctx->host_pinned);
@@ -558,20 +623,44 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
         r.cs_sweep = std::is_same<T, float>::value && r.force.kind == WTP_FORCE_CLIPPED_SPACING && r.k >= 2 &&
                      r.k < 32 && !ctx->full_select && !ctx->force_generic;
         const double rho_cs = r.cs_sweep ? 3.5 * (ctx->rho / 8.0) : 0.0;
-        const double min_cell = r.cs_sweep ? 1.1 * r.force.u0 * r.spacing_max : 0.0;
-        rc = build_hash<T>(ctx, (const Pt<T>*)ctx->pts[r.bufP].p, (Pt<T>*)ctx->pts[t].p, r.n, r.dim, r.k, 0.0, rho_cs,
-                           min_cell);
+        if (r.spacing_typ <= 0) { // once per session: the spacing a typical point asks for
+            r.spacing_typ = r.spacing_const;
+            if (r.spacing_kind != WTP_SPACING_CONSTANT) {
+                if ((rc = ensure(ctx, ctx->occ, 64))) return rc;
+                if ((rc = ensure_pinned(ctx, 1024))) return rc;
+                if ((rc = launch_sum<T>(ctx, (const T*)ctx->spacing_pp.p, r.n, (double*)ctx->occ.p))) return rc;
+                WTP_HIP(ctx, hipMemcpyAsync(ctx->host_pinned, ctx->occ.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+                if ((rc = sync(ctx))) return rc;
+                const double mean = ((const double*)ctx->host_pinned)[0] / (double)r.n;
+                const double var = ((const double*)ctx->host_pinned)[1] / (double)r.n - mean * mean;
+                r.spacing_typ = mean + ctx->styp_sigma * std::sqrt(var > 0 ? var : 0.0);
+                if (!(r.spacing_typ > 0)) r.spacing_typ = r.spacing_max;
+            }
+        }
+        // The compact-support sweep needs cells that cover the law's support u0*s.  With a variable
+        // spacing the cell edge follows the spacing a typical point asks for (the mean over points, which
+        // the dense regions dominate), not the largest one: the few points whose support is wider than
+        // that are handed to the exact path, instead of everybody's cells being 64x over-full.
+        const double min_cell = r.cs_sweep ? 1.1 * r.force.u0 * (r.spacing_typ < r.spacing_max ? r.spacing_typ : r.spacing_max)
+                                           : 0.0;
+        if (!r.grid_tuned) { // once per session: measured cell edge, LDS point area sized from the real grid
+            double rho_eff = 0;
+            Grid<T> hg;
+            rc = build_hash_tuned<T>(ctx, (const Pt<T>*)ctx->pts[r.bufP].p, (Pt<T>*)ctx->pts[t].p, r.n, r.dim, r.k, 0.0,
+                                     rho_cs, min_cell, &r.cell_scale, &rho_eff, &hg);
+            if (rc) return rc;
+            if (r.cs_sweep) {
+                int hc = (int)(HCELLS * rho_eff * 1.15) + 128;
+                hc = (hc + 63) / 64 * 64;
+                r.brick_hcap = hc < 640 ? 640 : (hc > 2560 ? 2560 : hc);
+            }
+            r.grid_tuned = true;
+        } else {
+            rc = build_hash<T>(ctx, (const Pt<T>*)ctx->pts[r.bufP].p, (Pt<T>*)ctx->pts[t].p, r.n, r.dim, r.k, 0.0, rho_cs,
+                               min_cell, r.cell_scale);
+        }
         span_end(ctx, sp);
         if (rc) return rc;
-        if (r.cs_sweep && r.brick_hcap == 0) { // once per session: size the LDS point area from the real grid
-            Grid<T> hg;
-            WTP_HIP(ctx, hipMemcpyAsync(&hg, ctx->grid.p, sizeof(hg), hipMemcpyDeviceToHost, ctx->stream));
-            WTP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            const double occ = (double)r.n / (double)(hg.ncells > 0 ? hg.ncells : 1);
-            int hc = (int)(HCELLS * occ * 1.4) + 128;
-            hc = (hc + 63) / 64 * 64;
-            r.brick_hcap = hc < 640 ? 640 : (hc > 2560 ? 2560 : hc);
-        }
         r.bufS = t;
         r.bufP = t;
         r.have_tree = true;

@@ -79,7 +79,8 @@ __global__ void bbox_kernel(const Pt<T>* __restrict__ pts, int64_t n, T* __restr
 // One thread: final bbox reduce + grid parameters.  rho_k = target points per cell.
 template <typename T>
 __global__ void grid_setup_kernel(const T* __restrict__ part, int nparts, Grid<T>* __restrict__ g,
-                                  int64_t npts, int dim, double rho_k, double radius, double min_cell, int cell_cap) {
+                                  int64_t npts, int dim, double rho_k, double radius, double min_cell, int cell_cap,
+                                  double cell_scale) {
     // one wave: lanes stride over the per-block partials, shuffle-reduce, lane 0 does the setup
     double mn[3], mx[3];
     for (int a = 0; a < 3; ++a) {
@@ -110,10 +111,12 @@ __global__ void grid_setup_kernel(const T* __restrict__ part, int nparts, Grid<T
     } else {
         double vol = 1.0;
         for (int a = 0; a < dim; ++a) vol *= (ext[a] > emax * 1e-6 ? ext[a] : emax * 1e-6);
-        c = pow(rho_k * vol / (double)npts, 1.0 / (double)dim);
+        // cell_scale < 1: the caller measured that the occupied cells hold more points than the box
+        // average says (graded clouds, surfaces, outliers stretching the box) and shrinks the edge
+        c = pow(rho_k * vol / (double)npts, 1.0 / (double)dim) * cell_scale;
         if (radius > 0) {
             double cr = radius * (1.0 + 1.0 / 64.0); // c - margin >= radius
-            double cc = pow(2.0 * vol / (double)npts, 1.0 / (double)dim);
+            double cc = pow(2.0 * vol / (double)npts, 1.0 / (double)dim) * cell_scale;
             c = cr > cc ? cr : cc;
         }
         if (radius <= 0 && min_cell > c) c = min_cell; // caller's floor on the cell edge
@@ -371,20 +374,80 @@ int load_points(wtp_ctx* ctx, const T* d_xyz, Pt<T>* out, int64_t n, int dim) {
     return WTP_OK;
 }
 
-static int cell_capacity(const wtp_ctx* ctx, int64_t n, int k) {
+static int cell_capacity(const wtp_ctx* ctx, int64_t n, int k, double cell_scale) {
     double rho = ctx->rho * (k > 0 ? (double)k / 21.0 : 1.0);
     if (rho < 1.0) rho = 1.0;
-    double cap = (double)n / rho * 1.6 + 4096.0;
+    double cap = (double)n / rho * 1.6 / (cell_scale * cell_scale * cell_scale) + 4096.0;
+    if (cap > 8.0 * (double)n + 4096.0) cap = 8.0 * (double)n + 4096.0; // mostly-empty grids: bounded memory
     if (cap > 1.5e9) cap = 1.5e9;
     return (int)cap;
 }
 
+// Occupancy as the points see it: sum cnt^2 / sum cnt = the mean, over points, of the number of
+// points sharing their cell (rho + 1 for a Poisson cloud of mean rho).
+__global__ void occupancy_kernel(const int32_t* __restrict__ cnt, const int32_t* __restrict__ ncells_p,
+                                 unsigned long long* __restrict__ out /* [sum cnt^2, sum cnt, max] */) {
+    const int ncells = *ncells_p;
+    unsigned long long s2 = 0, s1 = 0, mx = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ncells; i += gridDim.x * blockDim.x) {
+        const unsigned long long c = (unsigned long long)cnt[i];
+        s2 += c * c;
+        s1 += c;
+        mx = c > mx ? c : mx;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        s2 += __shfl_down(s2, d, 64);
+        s1 += __shfl_down(s1, d, 64);
+        const unsigned long long o = __shfl_down(mx, d, 64);
+        mx = o > mx ? o : mx;
+    }
+    if ((threadIdx.x & 63) == 0 && s1) {
+        atomicAdd(&out[0], s2);
+        atomicAdd(&out[1], s1);
+        atomicMax(&out[2], mx);
+    }
+}
+
+template <typename T>
+__global__ void sum_kernel(const T* __restrict__ v, int64_t n, double* __restrict__ out) {
+    double s = 0, s2 = 0; // out[0] = sum, out[1] = sum of squares
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double x = (double)v[i];
+        s += x;
+        s2 += x * x;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        s += __shfl_down(s, d, 64);
+        s2 += __shfl_down(s2, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(out, s);
+        atomicAdd(out + 1, s2);
+    }
+}
+
+template <typename T> int launch_sum(wtp_ctx* ctx, const T* d_v, int64_t n, double* d_out) {
+    WTP_HIP(ctx, hipMemsetAsync(d_out, 0, 2 * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(sum_kernel<T>, dim3(grid_for(n, kThreads, 1024)), dim3(kThreads), 0, ctx->stream, d_v, n, d_out);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
+int launch_occupancy(wtp_ctx* ctx, unsigned long long* d_out3) {
+    WTP_HIP(ctx, hipMemsetAsync(d_out3, 0, 3 * sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(occupancy_kernel, dim3(1024), dim3(kThreads), 0, ctx->stream, (const int32_t*)ctx->cell_cnt.p,
+                       (const int32_t*)ctx->ncells_dev, d_out3);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
 template <typename T>
 int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, int k, double radius, double rho_direct,
-               double min_cell) {
+               double min_cell, double cell_scale) {
+    if (!(cell_scale > 0)) cell_scale = 1.0;
     // k-equivalent of the occupancy the caller fixed (rho = 8 <-> k = 21)
     const int k_cap = rho_direct > 0 ? (int)(rho_direct * 21.0 / ctx->rho) : (radius > 0 ? 6 : k);
-    const int cap = cell_capacity(ctx, n, k_cap > 0 ? k_cap : 1);
+    const int cap = cell_capacity(ctx, n, k_cap > 0 ? k_cap : 1, cell_scale);
     int rc;
     if ((rc = ensure(ctx, ctx->grid, sizeof(Grid<double>)))) return rc;
     const int nbb = grid_for(n, kThreads, 1024);
@@ -410,7 +473,9 @@ int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, in
 
     WTP_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)(cap + 1), st));
     hipLaunchKernelGGL(bbox_kernel<T>, dim3(nbb), dim3(kThreads), 0, st, in, n, part);
-    hipLaunchKernelGGL(grid_setup_kernel<T>, dim3(1), dim3(64), 0, st, part, nbb, g, n, dim, rho_k, radius, min_cell, cap);
+    hipLaunchKernelGGL(grid_setup_kernel<T>, dim3(1), dim3(64), 0, st, part, nbb, g, n, dim, rho_k, radius, min_cell, cap,
+                       cell_scale);
+    ctx->ncells_dev = &g->ncells;
     const int nb = grid_for(n, kThreads, 16384);
     hipLaunchKernelGGL(cell_rank_kernel<T>, dim3(nb), dim3(kThreads), 0, st, in, n, g, cnt, cr);
     hipLaunchKernelGGL(scan_reduce_kernel<T>, dim3(nscan), dim3(kThreads), 0, st, cnt, g, bs);
@@ -783,11 +848,12 @@ int launch_refix(wtp_ctx* ctx, const Pt<T>* in, int64_t n_old, int64_t n_fixed_o
 
 // explicit instantiations
 #define INST(T)                                                                                         \
+    template int launch_sum<T>(wtp_ctx*, const T*, int64_t, double*);                                   \
     template int launch_layers<T>(wtp_ctx*, const Pt<T>*, int64_t, int64_t, int, double, double, double, double, \
                                   Pt<T>*, Pt<T>*, int64_t, int2*, int32_t*);                            \
     template int launch_refix<T>(wtp_ctx*, const Pt<T>*, int64_t, int64_t, int64_t, const Pt<T>*, Pt<T>*, int32_t*); \
     template int load_points<T>(wtp_ctx*, const T*, Pt<T>*, int64_t, int);                              \
-    template int build_hash<T>(wtp_ctx*, const Pt<T>*, Pt<T>*, int64_t, int, int, double, double, double); \
+    template int build_hash<T>(wtp_ctx*, const Pt<T>*, Pt<T>*, int64_t, int, int, double, double, double, double); \
     template int launch_unpermute<T>(wtp_ctx*, const Pt<T>*, int64_t, int64_t, int, T*);                \
     template int launch_unpermute_point_data<T>(wtp_ctx*, const Pt<T>*, int64_t, int64_t, const T*,    \
                                                 const T*, const int32_t*, T*, T*, int32_t*);            \

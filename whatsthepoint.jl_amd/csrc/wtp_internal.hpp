@@ -139,6 +139,9 @@ struct RelaxState {
     bool have_point_data = false;
     double spacing_max = 0;  // largest spacing value (host-side max of the per-point array)
     int brick_hcap = 0;      // LDS point capacity of the sweep's brick kernel (0 = not chosen yet)
+    bool grid_tuned = false; // cell_scale / spacing_typ measured on the first rebuild
+    double cell_scale = 1.0; // < 1: cells shrunk because the occupied ones hold more than the box average
+    double spacing_typ = 0;  // mean spacing over the snapshot (floor of the compact-support cell edge)
     bool cs_sweep = false;   // compact-support sweep in use (ClippedSpacingForce)
     double sp_p0 = 0, sp_p1 = 0, sp_p2 = 0; // LOGLIKE / BOUNDARY_LAYER parameters
     int cover_axis = -1;     // sharded session: snapshot complete for cover_lo <= coord[axis] <= cover_hi
@@ -158,11 +161,16 @@ struct wtp_ctx {
     double gamma_cap = 1.08;
     int force_generic = 0;
     int full_select = 0;       // WTP_FULL_SELECT=1: never use the compact-support sweep
+    double styp_sigma = 0.0;   // WTP_STYP_SIGMA: typical spacing = mean + this many standard deviations (measured: > 0 only hurts)
+    int64_t knn_tune_n = -1;   // topology calls: cloud size / dim / k the cached cell scale was measured for
+    int knn_tune_dim = 0, knn_tune_k = 0;
+    double knn_tune_scale = 1.0;
     // pooled device buffers
     wtp::DevBuf pts[3];        // Pt arrays
     wtp::DevBuf raw_in;        // AoS staging of host input
     wtp::DevBuf cell_of, rank_of, cell_cnt, cell_start, scan_tmp;
-    wtp::DevBuf grid, bbox_part;
+    wtp::DevBuf grid, bbox_part, occ;
+    const void* ncells_dev = nullptr; // device address of Grid::ncells of the last build_hash
     wtp::DevBuf idx_out, dist_out, counts_out;
     wtp::DevBuf forces, nn_dist, nn_id, spacing_pp;
     wtp::DevBuf partials, stats, fb_list, fb_count, fb2_list, fb2_count;
@@ -216,7 +224,10 @@ void spans_collect(wtp_ctx* ctx);
 // radius > 0 forces cell edge >= radius (RadiusTopology); k scales the target occupancy.
 template <typename T>
 int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, int k, double radius,
-               double rho_direct = 0.0, double min_cell = 0.0);
+               double rho_direct = 0.0, double min_cell = 0.0, double cell_scale = 1.0);
+// occupancy of the grid the last build_hash made: d_out3 = [sum cnt^2, sum cnt, max cnt]
+int launch_occupancy(wtp_ctx* ctx, unsigned long long* d_out3);
+template <typename T> int launch_sum(wtp_ctx* ctx, const T* d_v, int64_t n, double* d_out);
 
 template <typename T>
 int load_points(wtp_ctx* ctx, const T* d_xyz, Pt<T>* out, int64_t n, int dim);
