@@ -25,8 +25,9 @@ def _rows4(x):
     return r
 
 
+@pytest.mark.parametrize("stale", [False, True])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_layers_match_numpy_selection(wtp, ctx, dtype):
+def test_layers_match_numpy_selection(wtp, ctx, dtype, stale):
     torch = _torch()
     n, n_fixed, k = 60000, 1500, 21
     s = n ** (-1.0 / 3.0)
@@ -34,7 +35,9 @@ def test_layers_match_numpy_selection(wtp, ctx, dtype):
     sess = ctx.relax(x, n_fixed, s, FORCE, k, s / 2000, s / 20)
     try:
         sess.step(True)
-        sess.step(True)
+        sess.step(not stale)                        # stale: a second sweep on the same grid (rebuild_every = 2)
+        if stale:
+            sess.step(False)
         pos = sess.positions()                      # movable points, movable-index order
         tdt = torch.float32 if dtype == np.float32 else torch.float64
         idt = torch.int32 if dtype == np.float32 else torch.int64

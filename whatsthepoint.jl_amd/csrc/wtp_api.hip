@@ -664,6 +664,8 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
         r.bufS = t;
         r.bufP = t;
         r.have_tree = true;
+        r.sweeps_since_rebuild = 0;
+        r.moved_by_hand = false;
     }
     if (spacing_on_device(r.spacing_kind)) {
         // s = spacing(x_i) at the point's current position (src/repel.jl:251 on rebuilds, :260 in every
@@ -722,6 +724,7 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
     r.bufP = o;
     r.can_revert = true;
     r.have_point_data = true;
+    r.sweeps_since_rebuild += 1;
     return WTP_OK;
 }
 
@@ -865,6 +868,7 @@ WTP_API int wtp_relax_set(wtp_ctx* ctx, int64_t i, const void* xyz) {
     }
     WTP_HIP(ctx, hipMemcpyAsync(ctx->scratch.p, xyz, ts * r.dim, hipMemcpyHostToDevice, ctx->stream));
     const int32_t id = (int32_t)(i + r.n_fixed);
+    r.moved_by_hand = true;
     if (r.dtype == WTP_F32)
         rc = launch_set_point<float>(ctx, (float4*)ctx->pts[r.bufP].p, r.n, id, r.dim, (const float*)ctx->scratch.p);
     else
@@ -1050,12 +1054,17 @@ WTP_API int wtp_relax_layers_dev(wtp_ctx* ctx, int axis, double lo_in, double hi
     if ((rc = ensure(ctx, ctx->scratch, 64 + sizeof(int2) * (size_t)nblk))) return rc;
     int32_t* d_tot = (int32_t*)ctx->scratch.p;
     int2* d_blk = (int2*)((char*)ctx->scratch.p + 64);
+    // P is in the slot order of the last rebuild's grid (and nobody moved farther than one spacing,
+    // src/repel.jl:286-289) whenever a sweep produced it: then only the boundary cell layers are scanned
+    const bool slot_ordered = r.have_tree && r.have_point_data && axis == r.dim - 1 && r.bufP != r.bufS &&
+                              !r.moved_by_hand;
+    const double reach = 1.001 * r.spacing_max * (double)(r.sweeps_since_rebuild > 0 ? r.sweeps_since_rebuild : 1);
     if (r.dtype == WTP_F32)
         rc = launch_layers<float>(ctx, (const float4*)ctx->pts[r.bufP].p, r.n, r.n_fixed, axis, lo_in, hi_in, lo_out,
-                                  hi_out, (float4*)d_lo4, (float4*)d_hi4, cap, d_blk, d_tot);
+                                  hi_out, (float4*)d_lo4, (float4*)d_hi4, cap, d_blk, d_tot, slot_ordered, reach);
     else
         rc = launch_layers<double>(ctx, (const double4*)ctx->pts[r.bufP].p, r.n, r.n_fixed, axis, lo_in, hi_in, lo_out,
-                                   hi_out, (double4*)d_lo4, (double4*)d_hi4, cap, d_blk, d_tot);
+                                   hi_out, (double4*)d_lo4, (double4*)d_hi4, cap, d_blk, d_tot, slot_ordered, reach);
     if (rc) return rc;
     if ((rc = ensure_pinned(ctx, 64))) return rc;
     WTP_HIP(ctx, hipMemcpyAsync(ctx->host_pinned, d_tot, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -647,9 +647,26 @@ __device__ inline int64_t layer_slot(int block, int wave, int pass, int lane) {
 
 template <typename T>
 __global__ void layer_count_kernel(const Pt<T>* __restrict__ pts, int64_t n, int32_t n_fixed, int axis, T lo_in,
-                                   T hi_in, T lo_out, T hi_out, int2* __restrict__ blk, int32_t* __restrict__ totals) {
+                                   T hi_in, T lo_out, T hi_out, int2* __restrict__ blk, int32_t* __restrict__ totals,
+                                   const Grid<T>* __restrict__ gp, const int32_t* __restrict__ cell_start, T reach) {
     __shared__ int sm[4][kThreads / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (gp) {
+        // pts is in the slot order of a grid whose slowest axis is `axis`, and no point has moved more
+        // than `reach` since it was binned: only the cell layers within reach of the planes can hold
+        // layer points, i.e. a prefix and a suffix of the slot range.  Chunks in between are skipped.
+        const Grid<T> g = *gp;
+        const int plane_cells = g.ncells / g.n[axis];
+        const T lo_plane = lo_in > lo_out ? lo_in : lo_out, hi_plane = hi_in < hi_out ? hi_in : hi_out;
+        int64_t lo_end = 0, hi_begin = n; // layer candidates: slots [0, lo_end) and [hi_begin, n)
+        if (lo_plane > -Lim<T>::inf()) lo_end = cell_start[(int64_t)(cell_coord(g, lo_plane + reach, axis) + 1) * plane_cells];
+        if (hi_plane < Lim<T>::inf()) hi_begin = cell_start[(int64_t)cell_coord(g, hi_plane - reach, axis) * plane_cells];
+        const int64_t b0 = (int64_t)blockIdx.x * kLayerChunk, b1 = b0 + kLayerChunk;
+        if (b0 >= lo_end && b1 <= hi_begin) {
+            if (threadIdx.x == 0) blk[blockIdx.x] = make_int2(0, 0);
+            return;
+        }
+    }
     int c[4] = {0, 0, 0, 0};
     for (int pass = 0; pass < kLayerPasses; ++pass) {
         const int64_t i = layer_slot(blockIdx.x, wave, pass, lane);
@@ -766,11 +783,14 @@ __global__ void layer_fill_kernel(const Pt<T>* __restrict__ pts, int64_t n, int3
 
 template <typename T>
 int launch_layers(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int64_t n_fixed, int axis, double lo_in, double hi_in,
-                  double lo_out, double hi_out, Pt<T>* d_lo, Pt<T>* d_hi, int64_t cap, int2* d_blk, int32_t* d_totals) {
+                  double lo_out, double hi_out, Pt<T>* d_lo, Pt<T>* d_hi, int64_t cap, int2* d_blk, int32_t* d_totals,
+                  bool slot_ordered, double reach) {
     const int nblk = layer_blocks(n);
     WTP_HIP(ctx, hipMemsetAsync(d_totals, 0, 4 * sizeof(int32_t), ctx->stream));
     hipLaunchKernelGGL(layer_count_kernel<T>, dim3(nblk), dim3(kThreads), 0, ctx->stream, pts, n, (int32_t)n_fixed, axis,
-                       (T)lo_in, (T)hi_in, (T)lo_out, (T)hi_out, d_blk, d_totals);
+                       (T)lo_in, (T)hi_in, (T)lo_out, (T)hi_out, d_blk, d_totals,
+                       slot_ordered ? (const Grid<T>*)ctx->grid.p : (const Grid<T>*)nullptr,
+                       (const int32_t*)ctx->cell_start.p, (T)reach);
     hipLaunchKernelGGL(layer_fill_kernel<T>, dim3(nblk), dim3(kThreads), 0, ctx->stream, pts, n, (int32_t)n_fixed, axis,
                        (T)lo_in, (T)hi_in, (const int2*)d_blk, d_lo, d_hi, cap);
     WTP_HIP(ctx, hipGetLastError());
@@ -850,7 +870,7 @@ int launch_refix(wtp_ctx* ctx, const Pt<T>* in, int64_t n_old, int64_t n_fixed_o
 #define INST(T)                                                                                         \
     template int launch_sum<T>(wtp_ctx*, const T*, int64_t, double*);                                   \
     template int launch_layers<T>(wtp_ctx*, const Pt<T>*, int64_t, int64_t, int, double, double, double, double, \
-                                  Pt<T>*, Pt<T>*, int64_t, int2*, int32_t*);                            \
+                                  Pt<T>*, Pt<T>*, int64_t, int2*, int32_t*, bool, double);              \
     template int launch_refix<T>(wtp_ctx*, const Pt<T>*, int64_t, int64_t, int64_t, const Pt<T>*, Pt<T>*, int32_t*); \
     template int load_points<T>(wtp_ctx*, const T*, Pt<T>*, int64_t, int);                              \
     template int build_hash<T>(wtp_ctx*, const Pt<T>*, Pt<T>*, int64_t, int, int, double, double, double, double); \

@@ -140,6 +140,8 @@ struct RelaxState {
     double spacing_max = 0;  // largest spacing value (host-side max of the per-point array)
     int brick_hcap = 0;      // LDS point capacity of the sweep's brick kernel (0 = not chosen yet)
     bool grid_tuned = false; // cell_scale / spacing_typ measured on the first rebuild
+    int sweeps_since_rebuild = 0; // every sweep moves a point by at most its spacing (src/repel.jl:286-289)
+    bool moved_by_hand = false;   // wtp_relax_set since the last rebuild: that bound is gone
     double cell_scale = 1.0; // < 1: cells shrunk because the occupied ones hold more than the box average
     double spacing_typ = 0;  // mean spacing over the snapshot (floor of the compact-support cell edge)
     bool cs_sweep = false;   // compact-support sweep in use (ClippedSpacingForce)
@@ -284,7 +286,8 @@ int launch_isinside_winding(wtp_ctx* ctx, const T* d_test, int64_t n, const T* d
 int layer_blocks(int64_t n);
 template <typename T>
 int launch_layers(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int64_t n_fixed, int axis, double lo_in, double hi_in,
-                  double lo_out, double hi_out, Pt<T>* d_lo, Pt<T>* d_hi, int64_t cap, int2* d_blk, int32_t* d_totals);
+                  double lo_out, double hi_out, Pt<T>* d_lo, Pt<T>* d_hi, int64_t cap, int2* d_blk, int32_t* d_totals,
+                  bool slot_ordered, double reach);
 template <typename T>
 int launch_refix(wtp_ctx* ctx, const Pt<T>* in, int64_t n_old, int64_t n_fixed_old, int64_t n_fixed_new,
                  const Pt<T>* d_fixed_new, Pt<T>* out, int32_t* d_counter);

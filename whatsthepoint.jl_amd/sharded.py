@@ -437,13 +437,14 @@ def uniform_shard(ctx_gen, rank: int, world: int, n_total: int, seed: int, devic
     return xyz[order].contiguous(), gid[order].contiguous(), cuts
 
 
-def ghost_width(n_total: int, k: int, rho: float = 8.0, ghost_cells: float = 1.25, dim: int = 3) -> float:
+def ghost_width(n_total: int, k: int, rho: float = 8.0, ghost_cells: float = 1.0, dim: int = 3) -> float:
     """Initial ghost width: ghost_cells x the k-NN hash cell edge for this density (csrc/wtp_hash.hip
     build_hash: c = (rho_k / density)^(1/dim), rho_k = 0.381 k rho/8; c ~ 1.17 r_k).
     Correctness needs every owned query's k nearest points to be present locally, i.e.
     w >= max r_k.  That is not assumed but checked: the sweep counts the queries whose k-th
     neighbour lies farther than w (wtp_relax_set_coverage -> stats.n_uncovered) and the driver
-    undoes the step, widens the layer by 1.5x and repeats it.  1.25 cells = 1.46x the mean r_k
-    (a ball holding ~65 points at uniform density) rarely needs that."""
+    undoes the step, widens the layer by 1.5x and repeats it.  1.0 cell = 1.17x the mean r_k, twice
+    the support of the default force law: on the uniform benchmark cloud one query in 10^7 asks for
+    more in the first iterations (isolated points), none once the cloud has relaxed."""
     rho_k = (0.381 if dim == 3 else 0.436) * k * (rho / 8.0)
     return ghost_cells * (max(rho_k, 1.0) / n_total) ** (1.0 / dim)
