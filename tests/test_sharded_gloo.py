@@ -58,7 +58,14 @@ class ResidentOracleEngine(OracleEngine):
         pass
 
 
-def _worker(rank, world, port, n_total, iters, q, margin=None, resident=False):
+def _wall(wtp_amd, n_wall):
+    b = wtp_amd.synth.uniform(n_wall, 3, np.float32, 19)
+    f = np.arange(n_wall) % 6
+    b[np.arange(n_wall), f % 3] = (f // 3).astype(np.float32)    # on the faces of the unit cube
+    return b
+
+
+def _worker(rank, world, port, n_total, iters, q, margin=None, resident=False, n_wall=0):
     for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -72,8 +79,13 @@ def _worker(rank, world, port, n_total, iters, q, margin=None, resident=False):
     gen = lambda first, n: torch.from_numpy(wtp_amd.synth.uniform(n, 3, np.float32, 7, first))
     xyz, gid, cuts = sharded.uniform_shard(gen, rank, world, n_total, 7, "cpu", chunk=5000)
     eng = (ResidentOracleEngine if resident else OracleEngine)(s, k, s / 2000, s / 20)
-    drv = sharded.ShardedRelax(eng, dist, xyz, gid, cuts, sharded.ghost_width(n_total, k), margin=margin)
-    conv = [drv.step()["max_force"] for _ in range(iters)]
+    wall = torch.from_numpy(_wall(wtp_amd, n_wall)) if n_wall else None
+    drv = sharded.ShardedRelax(eng, dist, xyz, gid, cuts, sharded.ghost_width(n_total, k), margin=margin, wall_xyz=wall)
+    if n_wall:   # the stop rules of _relax! over the reduced scalars: tol = 0 -> exactly `iters` sweeps
+        assert len(drv.relax(max_iters=50, tol=1e30)) == 1          # |F| s < tol after the first sweep
+        conv = [drv.history[0]["max_force"]] + drv.relax(max_iters=iters - 1, tol=0.0)
+    else:
+        conv = [drv.step()["max_force"] for _ in range(iters)]
     allp = drv.gather_global(n_total)
     if rank == 0:
         q.put((conv, allp.numpy(), [h["n_ghost"] for h in drv.history], [h["n_move"] for h in drv.history],
@@ -121,9 +133,40 @@ def test_sharded_matches_single_domain(O, wtp, world, margin, resident):
         assert migrations >= 1
 
 
+@pytest.mark.parametrize("resident", [False, True])
+@pytest.mark.parametrize("world", [1, 3])
+def test_sharded_with_a_global_wall_and_stop_rules(O, wtp, world, resident):
+    """Volume-only repel: the boundary wall is the fixed head of the snapshot on every rank
+    (src/repel.jl:80-84); the driver's relax() applies the reference's stop rules."""
+    n_total, n_wall, iters = 6000, 900, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, iters, q, None, resident, n_wall))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        conv, allp, n_ghost, n_move, migrations = q.get(timeout=240)
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    x = wtp.synth.uniform(n_total, 3, np.float32, 7)
+    s = float(n_total) ** (-1.0 / 3.0)
+    ref = O.relax_loop(np.concatenate([_wall(wtp, n_wall), x]), n_wall, s, 2, 0.2, 1.0, 3.0, 21, s / 2000, s / 20,
+                       max_iters=iters, tol=0.0, rebuild_every=1, stall_after=0)
+    assert np.array_equal(allp, ref["p"])
+    assert np.allclose(conv, ref["conv"], rtol=0, atol=0)
+    assert all(m == n_total for m in n_move) and all(g >= (n_wall if world == 1 else 1) for g in n_ghost)
+
+
 # ---- the same logic with the PRODUCT engine: 2 ranks sharing the one GPU of the test box, payloads
 # staged through host memory because gloo carries CPU tensors (RCCL needs one GPU per rank) ----------
-def _gpu_worker(rank, world, port, n_total, iters, q, ghost_w_over_s=None):
+def _gpu_worker(rank, world, port, n_total, iters, q, ghost_w_over_s=None, n_wall=0):
     for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -145,8 +188,9 @@ def _gpu_worker(rank, world, port, n_total, iters, q, ghost_w_over_s=None):
     xyz, gid, cuts = sharded.uniform_shard(gen, rank, world, n_total, 7, "cuda", chunk=50000)
     eng = sharded.GpuEngine(ctx, s, dict(kind=2, beta=0.2, u0=1.0, gamma=3.0), k, s / 2000, s / 20)
     w = sharded.ghost_width(n_total, k) if ghost_w_over_s is None else ghost_w_over_s * s
-    drv = sharded.ShardedRelax(eng, dist, xyz, gid, cuts, w, comm_device="cpu")
-    conv = [drv.step()["max_force"] for _ in range(iters)]
+    wall = torch.from_numpy(_wall(wtp_amd, n_wall)).cuda() if n_wall else None
+    drv = sharded.ShardedRelax(eng, dist, xyz, gid, cuts, w, comm_device="cpu", wall_xyz=wall)
+    conv = drv.relax(max_iters=iters, tol=0.0) if n_wall else [drv.step()["max_force"] for _ in range(iters)]
     allp = drv.gather_global(n_total)
     if rank == 0:
         q.put((conv, allp.numpy(), drv.widened, drv.w / s))
@@ -157,15 +201,15 @@ def _gpu_worker(rank, world, port, n_total, iters, q, ghost_w_over_s=None):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ghost_w_over_s", [None, 0.6])
-def test_sharded_gpu_engine_two_ranks_one_gpu(O, wtp, ghost_w_over_s):
+@pytest.mark.parametrize("ghost_w_over_s,n_wall", [(None, 0), (0.6, 0), (None, 4000)])
+def test_sharded_gpu_engine_two_ranks_one_gpu(O, wtp, ghost_w_over_s, n_wall):
     # ghost_w_over_s = 0.6: a ghost layer thinner than the force law's support — the sweep must
     # notice (n_uncovered), and the driver must undo, widen and repeat until the answer is global
     n_total, iters, world = 120000, 3, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, n_total, iters, q, ghost_w_over_s))
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, n_total, iters, q, ghost_w_over_s, n_wall))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -181,7 +225,8 @@ def test_sharded_gpu_engine_two_ranks_one_gpu(O, wtp, ghost_w_over_s):
     assert (widened == 0) if ghost_w_over_s is None else (widened >= 2 and w_over_s > 1.0)
     x = wtp.synth.uniform(n_total, 3, np.float32, 7)
     s = float(n_total) ** (-1.0 / 3.0)
-    ref = O.relax_loop(x, 0, s, 2, 0.2, 1.0, 3.0, 21, s / 2000, s / 20, max_iters=iters, tol=0.0, rebuild_every=1,
+    snap = np.concatenate([_wall(wtp, n_wall), x]) if n_wall else x
+    ref = O.relax_loop(snap, n_wall, s, 2, 0.2, 1.0, 3.0, 21, s / 2000, s / 20, max_iters=iters, tol=0.0, rebuild_every=1,
                        stall_after=0)
     assert np.allclose(conv, ref["conv"], rtol=1e-3)
     err = np.abs(allp - ref["p"]).max(axis=1) / s

@@ -122,10 +122,15 @@ class ShardedRelax:
     """Owns this rank's points (positions + global ids) and runs sharded repel iterations."""
 
     def __init__(self, engine, dist, owned_xyz: torch.Tensor, owned_gid: torch.Tensor, cuts, ghost_width: float,
-                 rank: int = None, world: int = None, comm_device=None, margin: float = None, legacy: bool = False):
+                 rank: int = None, world: int = None, comm_device=None, margin: float = None, legacy: bool = False,
+                 wall_xyz: torch.Tensor = None):
         """comm_device: where collective payloads live — the points' own device for RCCL ("nccl"
         backend), "cpu" to stage through host memory when the backend is gloo (rehearsals with
-        several ranks on one GPU)."""
+        several ranks on one GPU).  legacy=True forces the one-shot path (a fresh local session per
+        iteration) even when the engine can keep its session resident.
+        wall_xyz: the global fixed head of the snapshot (the boundary wall of the volume-only repel,
+        src/repel.jl:80-84), the same array on every rank; each rank keeps the part its slab and
+        ghost layers can see."""
         self.engine, self.dist = engine, dist
         self.rank = dist.get_rank() if rank is None else rank
         self.world = dist.get_world_size() if world is None else world
@@ -142,6 +147,10 @@ class ShardedRelax:
         self.margin = 0.25 * self.w if margin is None else float(margin)
         self.migrations = 0
         self.widened = 0  # times the ghost layer had to grow because a sweep reported uncovered queries
+        self.wall = None if wall_xyz is None or wall_xyz.shape[0] == 0 else wall_xyz.to(self.dev).contiguous()
+        self._wall_local = None
+        self._wall_w = None
+        self._wall_set = False
         self.last_local_points = int(owned_xyz.shape[0])
         self.history = []
 
@@ -155,6 +164,19 @@ class ShardedRelax:
     @xyz.setter
     def xyz(self, v):
         self._xyz = v
+
+    def _wall_rows(self):
+        """Wall points this rank's queries can see: everything inside the covered z-range.  Cached
+        until the ghost width changes."""
+        if self.wall is None:
+            return None
+        if self._wall_w != self.w:
+            lo, hi = self._bounds()
+            w_eff = self.w + self.margin
+            z = self.wall[:, 2]
+            self._wall_local = self.wall[(z >= lo - w_eff) & (z <= hi + w_eff)].contiguous()
+            self._wall_w = self.w
+        return self._wall_local
 
     # ---- point-to-point exchange with the two slab neighbours ------------------------------------
     def _exchange(self, to_lo: torch.Tensor, split_lo: int, to_hi: torch.Tensor, split_hi: int):
@@ -294,9 +316,18 @@ class ShardedRelax:
             else:
                 ghosts = self._last_recv
             # 3. ghosts = the neighbours' layers (+ my own emigrants, cut from their new owner's layer
-            #    before they arrived) become the fixed head of the local snapshot
+            #    before they arrived) become the fixed head of the local snapshot, after the wall
+            wall = self._wall_rows()
+            if wall is not None and wall.shape[0]:
+                ghosts = torch.cat([self._rows4(wall), ghosts])
             n_ghost = int(ghosts.shape[0])
             eng.set_ghosts(ghosts)
+        elif self.wall is not None and not self._wall_set:
+            eng.set_ghosts(self._rows4(self.wall))  # one rank: the wall is the whole fixed head, set once
+            self._wall_set = True
+            n_ghost = int(self.wall.shape[0])
+        elif self.wall is not None:
+            n_ghost = int(self.wall.shape[0])
         n_own = int(self.gid.shape[0])
         self.last_local_points = n_own + n_ghost
         st = eng.step()
@@ -372,8 +403,11 @@ class ShardedRelax:
             ghosts = torch.cat(gx) if gx else self.xyz[:0]
         else:
             ghosts = self.xyz[:0]
+        wall = self._wall_rows() if self.world > 1 else self.wall
+        if wall is not None and wall.shape[0]:
+            ghosts = torch.cat([wall.to(ghosts.dtype), ghosts])
         n_ghost = int(ghosts.shape[0])
-        # 3. local snapshot = [ghosts (fixed head) ; owned (movable tail)] -> sweep
+        # 3. local snapshot = [wall ; ghosts (fixed head) ; owned (movable tail)] -> sweep
         local = torch.cat([ghosts, self.xyz]).contiguous()
         self.last_local_points = int(local.shape[0])
         new_xyz, st = self.engine.sweep(local, n_ghost)
@@ -386,6 +420,34 @@ class ShardedRelax:
         for _ in range(iters):
             last = self.step()
         return last
+
+    def relax(self, max_iters: int = 1000, tol: float = 1.0e-6, stall_after: int = 0, cv_target: float = 0.0):
+        """The stop rules of _relax! (src/repel.jl:305-338) over the globally reduced scalars; every
+        rank takes the same decisions.  Returns the convergence history (max_i |F_i| s_i)."""
+        conv, best_cv, last_impr = [], math.inf, 0
+        i = 1
+        while i <= max_iters:
+            prev = None if self.resident else (self._xyz, self.gid)
+            st = self.step()
+            conv.append(st["max_force"])
+            if (stall_after > 0 or cv_target > 0) and st["n_move"] > 0:
+                mu = st["sum_u"] / st["n_move"]
+                cv = math.sqrt(max(st["sum_u2"] / st["n_move"] - mu * mu, 0.0)) / mu
+                if cv_target > 0 and cv <= cv_target:
+                    if self.resident:
+                        self.engine.revert()  # p .= p_old (src/repel.jl:314)
+                    else:
+                        self._xyz, self.gid = prev
+                    break
+                if stall_after > 0:
+                    if cv < best_cv * (1 - 1.0e-3):
+                        best_cv, last_impr = cv, i
+                    elif i - last_impr >= stall_after:
+                        break
+            if conv[-1] < tol:
+                break
+            i += 1
+        return conv
 
     def points_per_launch(self) -> int:
         return self.last_local_points
