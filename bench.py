@@ -105,6 +105,41 @@ def other_paths(ctx, torch, np, wtp_amd):
                                        "tera_pairs_per_s": round(len(t) * len(ec) / dev / 1e12, 3),
                                        "inside_fraction": round(float(ins.mean()), 4),
                                        "note": "wtp_isinside_greens, host arrays in and out; VALU-bound (13 instr/pair)"}
+    # graded cloud (BASELINE config 5 / north star "uniform and graded clouds"): thinned uniform stream,
+    # h_bulk/h_wall = 4, with its own BoundaryLayerSpacing law evaluated on the device
+    ng = 1_000_000
+    xg = wtp_amd.synth.graded(ng, 4.0, 0.2, np.float32)
+    shell = int((np.minimum(xg, 1 - xg).min(axis=1) < 0.02).sum())
+    hw = float(((1 - 0.96 ** 3) / shell) ** (1.0 / 3.0))
+    mg = int(1 / hw)
+    gg = (np.arange(mg, dtype=np.float32) + 0.5) / mg
+    ug, vg = np.meshgrid(gg, gg, indexing="ij")
+    wall = []
+    for axis in range(3):
+        for side in (0.0, 1.0):
+            c = np.zeros((mg * mg, 3), np.float32)
+            c[:, axis] = side
+            c[:, (axis + 1) % 3] = ug.ravel()
+            c[:, (axis + 2) % 3] = vg.ravel()
+            wall.append(c)
+    wall = np.concatenate(wall)
+    law = wtp_amd.BoundaryLayerSpacing(wall, at_wall=hw, bulk=4 * hw, layer_thickness=0.2)
+    with ctx.relax(np.concatenate([wall, xg]), len(wall), law.desc(), dict(kind=2, beta=0.2, u0=1.0, gamma=3.0), 21,
+                   hw / 2000, hw / 20) as t:
+        t.run_async_free(3, 1)
+        t0 = time.perf_counter()
+        _, st = t.run(10, 1)
+        dt = (time.perf_counter() - t0) / 10
+    out["graded_repel_1M_boundary_layer_law"] = {
+        "value": round(ng / dt / 1e6, 1), "unit": "Mpoints/s", "ms_per_iter": round(dt * 1e3, 3),
+        "exact_path_fraction": round(st["n_fallback"] / ng, 4),
+        "note": "64x density contrast; cell edge measured from the occupancy; points whose support exceeds a cell "
+                "take the exact wave-per-query path, which dominates the time (DESIGN.md §4)"}
+    t0 = time.perf_counter()
+    off, _ = ctx.radius(xg, 2.5 * hw)
+    dt = time.perf_counter() - t0
+    out["graded_radius_topology_1M"] = {"value": round(ng / dt / 1e6, 1), "unit": "Mpoints/s", "ms": round(dt * 1e3, 2),
+                                        "pairs": int(off[-1]), "note": "r = 2.5 h_wall, host arrays in and out"}
     return out
 
 
