@@ -30,11 +30,10 @@ def test_uncovered_count_bounds(wtp, monkeypatch, full_select):
                 t.set_coverage(2, lo, hi)
                 st = t.step(True)
             d = np.minimum(z - lo, hi - z)                       # distance to the nearer end of the cover
-            most = int((np.maximum(rk, 0.0 if full_select else s) > d * (1 - 1e-5)).sum())
-            if full_select:       # explicit selection: exactly the queries whose k-th neighbour is past the cover
-                least = int((rk > d * (1 + 1e-5)).sum())
-            else:                 # count-certified sweep: at least support / nearest neighbour past the cover
-                least = int((np.maximum(nn, s) > d * (1 + 1e-5)).sum())
+            # what an answer rests on: the k-th neighbour (explicit selection), or — on every path that
+            # certifies by counting, the exact wave path included — the law's support and the nearest neighbour
+            most = int((np.maximum(rk, s) > d * (1 - 1e-5)).sum())
+            least = int((np.maximum(nn, s) > d * (1 + 1e-5)).sum())
             assert least <= st["n_uncovered"] <= most, ((lo, hi), least, st["n_uncovered"], most)
             if np.isfinite(lo) and lo < -3 * s:
                 assert st["n_uncovered"] == 0
@@ -58,9 +57,14 @@ def test_uncovered_fp64_exact_path(wtp, ctx):
     n, k = 20000, 21
     s = n ** (-1.0 / 3.0)
     x = wtp.synth.uniform(n, 3, np.float64, 4)
-    rk, _ = _rk_and_nn(ctx, x, k)
+    rk, nn = _rk_and_nn(ctx, x, k)
     d = np.minimum(x[:, 0] + s, 1.0 + s - x[:, 0])
-    with ctx.relax(x, 0, s, FORCE, k, s / 2000, s / 20) as t:
-        t.set_coverage(0, -s, 1.0 + s)
-        st = t.step(True)
-    assert 0 < int((rk > d * (1 + 1e-9)).sum()) <= st["n_uncovered"] <= int((rk > d * (1 - 1e-9)).sum())
+    for kind in (2, 1):     # clipped law: support-ball shortcut of the wave kernel; equilibrium law: the k-th neighbour
+        with ctx.relax(x, 0, s, dict(kind=kind, beta=0.2, u0=1.0, gamma=3.0), k, s / 2000, s / 20) as t:
+            t.set_coverage(0, -s, 1.0 + s)
+            st = t.step(True)
+        if kind == 1:
+            least, most = int((rk > d * (1 + 1e-9)).sum()), int((rk > d * (1 - 1e-9)).sum())
+        else:
+            least, most = int((np.maximum(nn, s) > d * (1 + 1e-9)).sum()), int((np.maximum(rk, s) > d * (1 - 1e-9)).sum())
+        assert 0 < least <= st["n_uncovered"] <= most, (kind, least, st["n_uncovered"], most)

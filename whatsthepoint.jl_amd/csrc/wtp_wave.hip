@@ -89,9 +89,26 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
         const int cx = cell_coord(g, q.x, 0), cy = cell_coord(g, q.y, 1), cz = cell_coord(g, q.z, 2);
         int m = 0;
         bool overflow = false;
-        for (int r = 2;; r *= 2) {
+        // Compact-support shortcut (ClippedSpacingForce, the default law): points beyond u0*s contribute
+        // exactly 0 to the sum over the k nearest (src/repel_forces.jl:96-100), so if the ball of radius
+        // u0*s holds 2..k points (self included) they ARE the nearest ones, the nearest neighbour is among
+        // them and the sum over them is the reference's sum (adding zeros changes nothing).  That ball
+        // needs a much smaller block than the k-th neighbour and no selection at all.  Anything else
+        // (empty ball, more than k points, list overflow) takes the general path below.
+        int Kq = K;            // neighbours emitted: K, or the ball's population on the shortcut
+        T cs_lim = (T)0;
+        int cs_r = 0;
+        if (MODE == 1 && a.force_kind == WTP_FORCE_CLIPPED_SPACING && K >= 2) {
+            const T s = a.spacing_pp ? a.spacing_pp[id] : a.spacing_const;
+            cs_lim = (a.u0 * a.u0) * (s * s);
+            for (int r = 1; r <= 6 && !cs_r; ++r)
+                if (safe_radius2(g, q.x, q.y, q.z, cx, cy, cz, r) >= cs_lim) cs_r = r;
+        }
+        bool cs_try = cs_r > 0, cs_done = false;
+        for (int r2 = 2;;) {
+            const int r = cs_try ? cs_r : r2;
             m = 0;
-            const T g2 = safe_radius2(g, q.x, q.y, q.z, cx, cy, cz, r);
+            const T g2 = cs_try ? cs_lim : safe_radius2(g, q.x, q.y, q.z, cx, cy, cz, r);
             const int z0 = cz - r < 0 ? 0 : cz - r, z1 = cz + r > g.n[2] - 1 ? g.n[2] - 1 : cz + r;
             const int y0 = cy - r < 0 ? 0 : cy - r, y1 = cy + r > g.n[1] - 1 ? g.n[1] - 1 : cy + r;
             const int x0 = cx - r < 0 ? 0 : cx - r, x1 = cx + r > g.n[0] - 1 ? g.n[0] - 1 : cx + r;
@@ -151,11 +168,22 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
                     }
                 }
             }
+            if (cs_try) {
+                cs_try = false;
+                if (!overflow && m >= 2 && m <= K) {
+                    Kq = m;
+                    cs_done = true;
+                    break;
+                }
+                overflow = false;
+                continue; // general path, from r = 2
+            }
             if (overflow) break;
             if (m >= K) break;                       // everything inside g2 is known: the k-th is final
             if (g2 == Lim<T>::inf()) break;          // block covers the grid
+            r2 *= 2;
         }
-        if (overflow || m < K) { // m < K only when fewer than k points exist in reach (validated upstream)
+        if (overflow || m < Kq) { // m < K only when fewer than k points exist in reach (validated upstream)
             if (lane == 0) {
                 const int pos = atomicAdd(a.fb2_count, 1);
                 a.fb2_list[pos] = slot;
@@ -172,13 +200,14 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
             key[j] = i < m ? Bits<T>::of(sm->d2[i]) : ~(U)0;
         }
         U lo = 0, hi = Bits<T>::kInf;
+        if (cs_done) lo = hi; // the whole list is the answer: no selection
         while (lo < hi) {
             const U mid = lo + (hi - lo) / 2;
             int cnt = 0;
 #pragma unroll
             for (int j = 0; j < kKeyRegs; ++j)
                 if (j * 64 < m) cnt += __popcll(__ballot(key[j] <= mid));
-            if (cnt >= K)
+            if (cnt >= Kq)
                 hi = mid;
             else
                 lo = mid + 1;
@@ -215,7 +244,7 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
             const int32_t mi = sm->sid[i];
             int rank = 0;
             for (int j = 0; j < ns; ++j) rank += lex_lt(sm->sd2[j], sm->sid[j], md, mi) ? 1 : 0;
-            if (rank < K) {
+            if (rank < Kq) {
                 sm->od2[rank] = md;
                 sm->oid[rank] = mi;
                 sm->oslot[rank] = sm->sslot[i];
@@ -230,7 +259,7 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
             }
         } else {
             const T s = a.spacing_pp ? a.spacing_pp[id] : a.spacing_const;
-            for (int j = lane; j < K; j += 64) {
+            for (int j = lane; j < Kq; j += 64) {
                 T fx = 0, fy = 0, fz = 0;
                 if (sm->oid[j] != id) {
                     const Pt<T> c = a.snap[sm->oslot[j]];
@@ -245,7 +274,7 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
                 T Fx = 0, Fy = 0, Fz = 0;
                 int32_t nid = -1;
                 T nd = Lim<T>::inf();
-                for (int j = 0; j < K; ++j) { // ascending (d2, id), self skipped by index (:271)
+                for (int j = 0; j < Kq; ++j) { // ascending (d2, id), self skipped by index (:271)
                     if (sm->oid[j] == id) continue;
                     if (nid < 0) {
                         nid = sm->oid[j];
@@ -263,7 +292,8 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
                 a.nn_dist[slot] = nd;
                 a.nn_id[slot] = nid;
                 acc_point(acc, (double)f, (double)nd, (double)s, id, nid);
-                if (reaches_past_cover<T>(a, q.x, q.y, q.z, sm->od2[K - 1])) atomicAdd(a.uncovered, 1);
+                // sharded sessions: what the answer rests on — the k-th neighbour, or the support ball
+                if (reaches_past_cover<T>(a, q.x, q.y, q.z, cs_done ? cs_lim : sm->od2[K - 1])) atomicAdd(a.uncovered, 1);
             }
         }
         __builtin_amdgcn_wave_barrier();
