@@ -620,8 +620,8 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
         // Compact-support sweep (fp32, ClippedSpacingForce, k >= 2): cells only have to cover the
         // law's support u0*s and the nearest-neighbour radius, so they can be smaller than the k-NN
         // cells (rho ~ 3.5 instead of ~8): 2.3x fewer candidates per query.
-        r.cs_sweep = std::is_same<T, float>::value && r.force.kind == WTP_FORCE_CLIPPED_SPACING && r.k >= 2 &&
-                     r.k < 32 && !ctx->full_select && !ctx->force_generic;
+        r.cs_sweep = r.force.kind == WTP_FORCE_CLIPPED_SPACING && r.k >= 2 && r.k < 32 && !ctx->full_select &&
+                     !ctx->force_generic;
         const double rho_cs = r.cs_sweep ? 3.5 * (ctx->rho / 8.0) : 0.0;
         if (r.spacing_typ <= 0) { // once per session: the spacing a typical point asks for
             r.spacing_typ = r.spacing_const;

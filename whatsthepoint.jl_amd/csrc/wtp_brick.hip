@@ -725,13 +725,28 @@ template <> int launch_sweep<float>(wtp_ctx* ctx, SearchArgs<float>& a, bool fre
     return rc;
 }
 
-template <> int launch_sweep<double>(wtp_ctx* ctx, SearchArgs<double>& a, bool) {
+template <> int launch_sweep<double>(wtp_ctx* ctx, SearchArgs<double>& a, bool fresh) {
     WTP_HIP(ctx, hipMemsetAsync(a.partials, 0, sizeof(Partial) * (size_t)a.n_partials, ctx->stream));
     WTP_HIP(ctx, hipMemsetAsync(a.fb_count, 0, sizeof(int32_t), ctx->stream));
     ctx->n_sweep_launches += 1;
+    // ClippedSpacingForce on a fresh snapshot: compact-support brick sweep (wtp_brick64.hip), the wave
+    // kernel takes what it hands back.  Everything else in fp64: the exact wave-per-query path.
+    const bool cs = fresh && a.brick_hcap > 0 && a.force_kind == WTP_FORCE_CLIPPED_SPACING && a.k >= 2 &&
+                    a.k <= kFastKMax - 1 && !ctx->full_select && !ctx->force_generic;
+    if (!cs) {
+        const int sp = span_begin(ctx, 1);
+        int rc = launch_generic_sweep<double>(ctx, a, true);
+        span_end(ctx, sp);
+        return rc;
+    }
+    a.gamma_cap = ctx->gamma_cap;
     const int sp = span_begin(ctx, 1);
-    int rc = launch_generic_sweep<double>(ctx, a, true);
+    int rc = launch_brick_cs<double>(ctx, a);
     span_end(ctx, sp);
+    if (rc) return rc;
+    const int sp2 = span_begin(ctx, 2);
+    rc = launch_generic_sweep<double>(ctx, a, false);
+    span_end(ctx, sp2);
     return rc;
 }
 

@@ -236,6 +236,8 @@ int load_points(wtp_ctx* ctx, const T* d_xyz, Pt<T>* out, int64_t n, int dim);
 
 template <typename T> int launch_topology(wtp_ctx* ctx, SearchArgs<T>& a);
 template <typename T> int launch_sweep(wtp_ctx* ctx, SearchArgs<T>& a, bool fresh);
+// fp64 compact-support brick sweep (wtp_brick64.hip); hand-backs land in a.fb_list
+template <typename T> int launch_brick_cs(wtp_ctx* ctx, SearchArgs<T>& a);
 // exact paths: wave-per-query (list = fb_list or all points), then the serial kernel on fb2_list
 template <typename T> int launch_wave_topology(wtp_ctx* ctx, SearchArgs<T>& a, bool all);
 template <typename T> int launch_wave_sweep(wtp_ctx* ctx, SearchArgs<T>& a, bool all);
