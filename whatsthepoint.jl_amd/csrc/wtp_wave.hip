@@ -3,9 +3,10 @@
 // Serves every query the 27-cell brick kernels hand back, and whole sweeps the brick path does
 // not cover (fp64, k > 48, stale snapshots of rebuild_every > 1, src/repel.jl:245,262-266).
 //   gather   the wave walks the x-rows of the (2r+1)^dim cell block around the query's cell;
-//            each row is one contiguous run of the sorted Pt array, read 64 points per step
-//            (coalesced 16/32-B loads).  Candidates inside the provable radius are appended to a
-//            per-wave LDS list with ballot + mbcnt prefix sums.
+//            each row is one contiguous run of the sorted Pt array; the runs of up to 64 rows are
+//            flattened (scan of their lengths) and read 64 candidates per step whatever rows they
+//            come from.  Candidates inside the provable radius are appended to a per-wave LDS list
+//            with ballot + mbcnt prefix sums.
 //   select   the k-th smallest d2 is found by bisection on the d2 bit pattern (monotone for
 //            d2 >= 0): count(d2 <= mid) is a ballot + s_bcnt per 64 candidates, keys held in
 //            VGPRs.  Survivors (d2 <= cut) are ranked by the canonical (d2, index) order with a
@@ -24,7 +25,6 @@ static constexpr int kThreads = kWaves * 64;
 static constexpr int kCap = 1024;            // candidates buffered per wave
 static constexpr int kKeyRegs = kCap / 64;
 static constexpr int kSurv = 256;            // survivors (d2 <= cut) ranked per wave
-static constexpr int kRowBatch = 8;          // rows whose first 64 points are loaded together
 
 template <typename T> struct Bits;
 template <> struct Bits<float> {
@@ -113,8 +113,7 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
             const int y0 = cy - r < 0 ? 0 : cy - r, y1 = cy + r > g.n[1] - 1 ? g.n[1] - 1 : cy + r;
             const int x0 = cx - r < 0 ? 0 : cx - r, x1 = cx + r > g.n[0] - 1 ? g.n[0] - 1 : cx + r;
             // Rows of the block are independent contiguous runs of the sorted array.  Lanes fetch
-            // the run bounds of up to 64 rows in one go; the first 64 points of kRowBatch rows are
-            // then loaded together (independent global loads in flight) before any is consumed.
+            // the run bounds of up to 64 rows in one go.
             auto consume = [&](int p, bool valid, const Pt<T>& c) {
                 bool take = false;
                 T d = 0;
@@ -144,28 +143,41 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
                     my_ps = a.cell_start[row + x0];
                     my_pe = a.cell_start[row + x1 + 1];
                 }
-                const int nr = nrows - rb < 64 ? nrows - rb : 64;
-                for (int b = 0; b < nr && !overflow; b += kRowBatch) {
-                    Pt<T> c[kRowBatch];
-                    int ps[kRowBatch], pe[kRowBatch];
+                // The rows' runs are flattened into one candidate stream: an exclusive scan of the run
+                // lengths across the lanes, then every step takes the next 64 candidates whatever rows
+                // they come from (a 6-step search over the scanned offsets finds each lane's row).  A
+                // sparse block of 25 rows x 5 points costs 2 steps instead of 25; two steps' loads are
+                // in flight together.
+                const int my_len = my_pe - my_ps;
+                int incl = my_len;
 #pragma unroll
-                    for (int u = 0; u < kRowBatch; ++u) {
-                        const int src = b + u < nr ? b + u : 0;
-                        ps[u] = __shfl(my_ps, src, 64);
-                        pe[u] = b + u < nr ? __shfl(my_pe, src, 64) : ps[u];
-                        const int p = ps[u] + lane;
-                        c[u] = a.snap[p < pe[u] ? p : ps[u] < a.n ? ps[u] : 0];
-                    }
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int o = __shfl_up(incl, d, 64);
+                    if (lane >= d) incl += o;
+                }
+                const int total = __shfl(incl, 63, 64);
+                const int excl = incl - my_len;
+                for (int base = 0; base < total && !overflow; base += 2 * 64) {
+                    Pt<T> c[2];
+                    int pp[2];
+                    bool vv[2];
 #pragma unroll
-                    for (int u = 0; u < kRowBatch; ++u) {
-                        if (overflow) break;
-                        consume(ps[u] + lane, ps[u] + lane < pe[u], c[u]);
-                        for (int p0 = ps[u] + 64; p0 < pe[u] && !overflow; p0 += 64) { // long rows
-                            const int p = p0 + lane;
-                            const Pt<T> cc = a.snap[p < pe[u] ? p : ps[u]];
-                            consume(p, p < pe[u], cc);
+                    for (int u = 0; u < 2; ++u) {
+                        const int f = base + u * 64 + lane;
+                        vv[u] = f < total;
+                        int lo = 0, hi = 63;
+#pragma unroll
+                        for (int it = 0; it < 6; ++it) { // largest row whose first candidate is <= f
+                            const int mid = (lo + hi + 1) >> 1;
+                            const bool ge = __shfl(excl, mid, 64) <= f;
+                            lo = ge ? mid : lo;
+                            hi = ge ? hi : mid - 1;
                         }
+                        pp[u] = __shfl(my_ps, lo, 64) + (f - __shfl(excl, lo, 64));
+                        c[u] = a.snap[vv[u] ? pp[u] : 0];
                     }
+                    consume(pp[0], vv[0], c[0]);
+                    if (base + 64 < total && !overflow) consume(pp[1], vv[1], c[1]);
                 }
             }
             if (cs_try) {
