@@ -706,18 +706,22 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
     a.fb_list = (int32_t*)ctx->fb_list.p;
     a.fb_count = (int32_t*)ctx->fb_count.p;
     a.fb2_list = (int32_t*)ctx->fb2_list.p;
-    a.fb2_count = (int32_t*)ctx->fb2_count.p;
+    // one 64-byte counter block, cleared once per sweep: [0] hand-backs of the brick kernel,
+    // [4] of the wave kernel, [8] uncovered queries
+    a.fb2_count = (int32_t*)ctx->fb_count.p + 4;
     if ((rc = ensure(ctx, ctx->diag, 128))) return rc;
     a.diag = (unsigned long long*)ctx->diag.p;
     a.brick_hcap = r.cs_sweep ? r.brick_hcap : 0;
     a.cover_axis = r.cover_axis;
     a.cover_lo = (T)r.cover_lo;
     a.cover_hi = (T)r.cover_hi;
-    a.uncovered = (int32_t*)ctx->fb_count.p + 8; // second word group of the 64-byte counter block
-    WTP_HIP(ctx, hipMemsetAsync(a.uncovered, 0, sizeof(int32_t), ctx->stream));
+    a.uncovered = (int32_t*)ctx->fb_count.p + 8;
+    WTP_HIP(ctx, hipMemsetAsync(ctx->fb_count.p, 0, 64, ctx->stream));
+    a.used_brick = a.used_wave = a.used_generic = 0;
     if ((rc = launch_sweep<T>(ctx, a, fresh))) return rc;
     int sp = span_begin(ctx, 2);
-    rc = launch_reduce_partials(ctx, a.partials, a.n_partials, a.fb_count, a.uncovered, d_slot);
+    rc = launch_reduce_partials(ctx, a.partials, a.n_partials, a.used_brick, a.used_wave, a.used_generic, a.fb_count,
+                                a.uncovered, d_slot);
     span_end(ctx, sp);
     if (rc) return rc;
     r.bufOld = r.bufP; // p_old (src/repel.jl:244)

@@ -678,6 +678,7 @@ template <int MODE, int KT, int CS> static int brick_launch(wtp_ctx* ctx, Search
     int gsz = ctx->sm_count * occ;
     gsz -= gsz % 8;
     if (gsz < 8) gsz = 8;
+    if (MODE == 1) a.used_brick = gsz;
     hipLaunchKernelGGL((brick_kernel<MODE, KT, CS>), dim3(gsz), dim3(kBrickThreads), brick_smem_bytes(hcap, nb),
                        ctx->stream, a, hcap);
     WTP_HIP(ctx, hipGetLastError());
@@ -700,8 +701,8 @@ template <> int launch_topology<double>(wtp_ctx* ctx, SearchArgs<double>& a) {
 }
 
 template <> int launch_sweep<float>(wtp_ctx* ctx, SearchArgs<float>& a, bool fresh) {
-    WTP_HIP(ctx, hipMemsetAsync(a.partials, 0, sizeof(Partial) * (size_t)a.n_partials, ctx->stream));
-    WTP_HIP(ctx, hipMemsetAsync(a.fb_count, 0, sizeof(int32_t), ctx->stream));
+    // the caller cleared the counter block; partial slots need no clearing: the reduction reads only
+    // the slots this step's launches write (a.used_*)
     ctx->n_sweep_launches += 1;
     if (!fresh || a.k > kFastKMax - 1 || ctx->force_generic) {
         const int sp = span_begin(ctx, 1);
@@ -726,8 +727,6 @@ template <> int launch_sweep<float>(wtp_ctx* ctx, SearchArgs<float>& a, bool fre
 }
 
 template <> int launch_sweep<double>(wtp_ctx* ctx, SearchArgs<double>& a, bool fresh) {
-    WTP_HIP(ctx, hipMemsetAsync(a.partials, 0, sizeof(Partial) * (size_t)a.n_partials, ctx->stream));
-    WTP_HIP(ctx, hipMemsetAsync(a.fb_count, 0, sizeof(int32_t), ctx->stream));
     ctx->n_sweep_launches += 1;
     // ClippedSpacingForce on a fresh snapshot: compact-support brick sweep (wtp_brick64.hip), the wave
     // kernel takes what it hands back.  Everything else in fp64: the exact wave-per-query path.

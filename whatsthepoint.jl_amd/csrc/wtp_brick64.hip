@@ -322,6 +322,7 @@ template <typename T> int launch_brick_cs(wtp_ctx* ctx, SearchArgs<T>& a) {
     gsz -= gsz % 8;
     if (gsz < 8) gsz = 8;
     if (gsz > brick_partials()) gsz = brick_partials() - brick_partials() % 8;
+    a.used_brick = gsz;
     hipLaunchKernelGGL((brick_cs_kernel<T>), dim3(gsz), dim3(kB64Threads), smem, ctx->stream, a, hcap);
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;

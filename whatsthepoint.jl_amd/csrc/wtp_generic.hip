@@ -189,17 +189,19 @@ template <typename T> int launch_generic_topology(wtp_ctx* ctx, SearchArgs<T>& a
 
 template <typename T> int launch_generic_sweep(wtp_ctx* ctx, SearchArgs<T>& a, bool all) {
     const int part_base = a.n_partials - kGenericPartials;
-    // partial slots of blocks that never run were cleared by the caller's memset
-    WTP_HIP(ctx, hipMemsetAsync(a.fb2_count, 0, sizeof(int32_t), ctx->stream));
+    // counters were cleared by the caller (one block for fb_count / fb2_count / uncovered)
     if (ctx->force_generic == 2) {
-        hipLaunchKernelGGL((generic_kernel<T, 1>), dim3(blocks_for(a.n, kGenericPartials)), dim3(kThreads), 0,
-                           ctx->stream, a, a.fb_list, a.fb_count, all ? 1 : 0, part_base);
+        a.used_generic = blocks_for(a.n, kGenericPartials);
+        hipLaunchKernelGGL((generic_kernel<T, 1>), dim3(a.used_generic), dim3(kThreads), 0, ctx->stream, a, a.fb_list,
+                           a.fb_count, all ? 1 : 0, part_base);
         WTP_HIP(ctx, hipGetLastError());
         return WTP_OK;
     }
     int rc = launch_wave_sweep<T>(ctx, a, all);
     if (rc) return rc;
-    hipLaunchKernelGGL((generic_kernel<T, 1>), dim3(256), dim3(kThreads), 0, ctx->stream, a, a.fb2_list,
+    // serial last resort over what the wave kernel could not buffer: a handful of queries at most
+    a.used_generic = blocks_for(a.n / 16, 256);
+    hipLaunchKernelGGL((generic_kernel<T, 1>), dim3(a.used_generic), dim3(kThreads), 0, ctx->stream, a, a.fb2_list,
                        a.fb2_count, 0, part_base);
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;

@@ -588,12 +588,17 @@ int launch_gen_uniform(wtp_ctx* ctx, uint64_t seed, int64_t first, int64_t n, in
 }
 
 // ---- final reduction of per-block partials (fixed order => deterministic) --------------------
-__global__ void reduce_partials_kernel(const Partial* __restrict__ parts, int n_parts,
-                                       const int32_t* __restrict__ fb_count,
+__global__ void reduce_partials_kernel(const Partial* __restrict__ parts, int n_parts, int used_brick, int wave_base,
+                                       int used_wave, int used_generic, const int32_t* __restrict__ fb_count,
                                        const int32_t* __restrict__ uncovered, wtp_step_stats* __restrict__ out) {
     __shared__ Acc sm[kThreads / 64];
     Acc acc = acc_empty();
-    for (int i = threadIdx.x; i < n_parts; i += blockDim.x) {
+    // only the slots this step's launches wrote (fixed order => deterministic): three ranges
+    const int total = used_brick + used_wave + used_generic;
+    for (int t = threadIdx.x; t < total; t += blockDim.x) {
+        const int i = t < used_brick ? t
+                                     : (t < used_brick + used_wave ? wave_base + (t - used_brick)
+                                                                   : n_parts - kGenericPartials + (t - used_brick - used_wave));
         if (parts[i].n_move == 0) continue; // slot of a block that saw no movable point
         Acc o;
         o.max_force = parts[i].max_force;
@@ -619,10 +624,10 @@ __global__ void reduce_partials_kernel(const Partial* __restrict__ parts, int n_
     }
 }
 
-int launch_reduce_partials(wtp_ctx* ctx, const Partial* parts, int n_parts, const int32_t* fb_count,
-                           const int32_t* uncovered, wtp_step_stats* d_slot) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, parts, n_parts,
-                       fb_count, uncovered, d_slot);
+int launch_reduce_partials(wtp_ctx* ctx, const Partial* parts, int n_parts, int used_brick, int used_wave,
+                           int used_generic, const int32_t* fb_count, const int32_t* uncovered, wtp_step_stats* d_slot) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, parts, n_parts, used_brick,
+                       brick_partials(), used_wave, used_generic, fb_count, uncovered, d_slot);
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;
 }

@@ -103,6 +103,9 @@ template <typename T> struct SearchArgs {
     int32_t n_fixed;
     Partial* partials;         // [n_partials]
     int32_t n_partials;
+    // blocks each sweep kernel was launched with = partial slots it wrote (set by the launchers):
+    // brick [0, used_brick), wave [brick_partials(), +used_wave), serial [n_partials - kGenericPartials, +used_generic)
+    int32_t used_brick, used_wave, used_generic;
     // fallback work list
     int32_t* fb_list;
     int32_t* fb_count;
@@ -252,8 +255,9 @@ int launch_radius_count(wtp_ctx* ctx, SearchArgs<T>& a, T r, int32_t* d_counts);
 template <typename T>
 int launch_radius_fill(wtp_ctx* ctx, SearchArgs<T>& a, T r, const int64_t* d_offsets,
                        int32_t* d_idx);
-int launch_reduce_partials(wtp_ctx* ctx, const Partial* parts, int n_parts, const int32_t* fb_count,
-                           const int32_t* uncovered, wtp_step_stats* d_stats_slot);
+int launch_reduce_partials(wtp_ctx* ctx, const Partial* parts, int n_parts, int used_brick, int used_wave,
+                           int used_generic, const int32_t* fb_count, const int32_t* uncovered,
+                           wtp_step_stats* d_stats_slot);
 template <typename T>
 int launch_unpermute(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int64_t n_fixed, int dim, T* d_xyz_out);
 template <typename T>

@@ -428,8 +428,13 @@ template <typename T, int MODE> static int launch_wave(wtp_ctx* ctx, SearchArgs<
                                   (int)wave_smem<T>());
         attr_set = true;
     }
-    int64_t want = all ? ((int64_t)a.n + kWaves - 1) / kWaves : 2048;
+    // hand-back lists are a small fraction of the cloud: size the grid by the cloud, not by the chip
+    // (an idle block still pays its reduction and its partial: 27 us per step at 47 k points with 2048)
+    int64_t want = all ? ((int64_t)a.n + kWaves - 1) / kWaves : (int64_t)a.n / 256;
+    if (!all && want > 2048) want = 2048;
+    if (!all && want < 64) want = 64;
     int nb = (int)(want > kWavePartials ? kWavePartials : (want < 1 ? 1 : want));
+    if (MODE == 1) a.used_wave = nb;
     hipLaunchKernelGGL((wave_kernel<T, MODE>), dim3(nb), dim3(kThreads), wave_smem<T>(), ctx->stream, a, a.fb_list,
                        a.fb_count, all ? 1 : 0, part_base);
     WTP_HIP(ctx, hipGetLastError());
