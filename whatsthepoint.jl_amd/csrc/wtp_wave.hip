@@ -7,9 +7,9 @@
 //            flattened (scan of their lengths) and read 64 candidates per step whatever rows they
 //            come from.  Candidates inside the provable radius are appended to a per-wave LDS list
 //            with ballot + mbcnt prefix sums.
-//   select   the k-th smallest d2 is found by bisection on the d2 bit pattern (monotone for
-//            d2 >= 0): count(d2 <= mid) is a ballot + s_bcnt per 64 candidates, keys held in
-//            VGPRs.  Survivors (d2 <= cut) are ranked by the canonical (d2, index) order with a
+//   select   the k-th smallest d2 is found by quickselect on the d2 bit patterns (monotone for
+//            d2 >= 0), pivoting on candidates: count(d2 <= pivot) is a ballot + s_bcnt per 64
+//            candidates, keys held in VGPRs.  Survivors (d2 <= cut) are ranked by the canonical (d2, index) order with a
 //            broadcast compare loop, giving the sorted first k.
 //   emit     MODE 0 writes the row (coalesced); MODE 1 evaluates the k contributions in
 //            parallel, then lane 0 adds them in ascending order exactly like
@@ -105,7 +105,9 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
                 if (safe_radius2(g, q.x, q.y, q.z, cx, cy, cz, r) >= cs_lim) cs_r = r;
         }
         bool cs_try = cs_r > 0, cs_done = false;
-        for (int r2 = 2;;) {
+        // hand-backs of the brick kernels already failed at 27 cells: start at 5^3; whole-cloud runs
+        // (fp64, stale snapshots) start at the 27 cells, which certify most queries
+        for (int r2 = all ? 1 : 2;;) {
             const int r = cs_try ? cs_r : r2;
             m = 0;
             const T g2 = cs_try ? cs_lim : safe_radius2(g, q.x, q.y, q.z, cx, cy, cz, r);
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
                     break;
                 }
                 overflow = false;
-                continue; // general path, from r = 2
+                continue; // general path
             }
             if (overflow) break;
             if (m >= K) break;                       // everything inside g2 is known: the k-th is final
@@ -204,26 +206,46 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
         }
         __builtin_amdgcn_wave_barrier();
 
-        // ---- select: k-th smallest d2 by bisection over bit patterns, keys in registers --------
+        // ---- select: k-th smallest d2 over the bit patterns, keys in registers -----------------------
         U key[kKeyRegs];
 #pragma unroll
         for (int j = 0; j < kKeyRegs; ++j) {
             const int i = j * 64 + lane;
             key[j] = i < m ? Bits<T>::of(sm->d2[i]) : ~(U)0;
         }
+        // Quickselect with ballots.  Invariant: count(key <= lo) < Kq <= count(key <= hi); a pivot is
+        // any candidate strictly inside (lo, hi).  ~2 ln m rounds expected,
+        // against the 32 (fp32) / 64 (fp64) rounds a bisection over the bit pattern needs.
         U lo = 0, hi = Bits<T>::kInf;
-        if (cs_done) lo = hi; // the whole list is the answer: no selection
-        while (lo < hi) {
-            const U mid = lo + (hi - lo) / 2;
+        bool lo_valid = false;
+        while (!cs_done) { // cs_done: the whole list is the answer, no selection
+            bool found = false;
+            U pivot = 0;
+#pragma unroll
+            for (int j = 0; j < kKeyRegs; ++j) {
+                if (!found && j * 64 < m) {
+                    const unsigned long long mask = __ballot((!lo_valid || key[j] > lo) && key[j] < hi);
+                    if (mask) {
+                        const unsigned long long upper = mask & (~0ull << 31);
+                        const int src = __builtin_ctzll(upper ? upper : mask);
+                        pivot = __shfl(key[j], src, 64);
+                        found = true;
+                    }
+                }
+            }
+            if (!found) break; // nothing strictly between: the Kq-th smallest is hi
             int cnt = 0;
 #pragma unroll
             for (int j = 0; j < kKeyRegs; ++j)
-                if (j * 64 < m) cnt += __popcll(__ballot(key[j] <= mid));
-            if (cnt >= Kq)
-                hi = mid;
-            else
-                lo = mid + 1;
+                if (j * 64 < m) cnt += __popcll(__ballot(key[j] <= pivot));
+            if (cnt >= Kq) {
+                hi = pivot;
+            } else {
+                lo = pivot;
+                lo_valid = true;
+            }
         }
+        lo = hi;
         const U cut = lo;
         // ---- survivors: d2 <= cut (k of them, more only on ties at the cut) --------------------------
         int ns = 0;
