@@ -37,7 +37,7 @@ def test_uncovered_count_bounds(wtp, monkeypatch, full_select):
             assert least <= st["n_uncovered"] <= most, ((lo, hi), least, st["n_uncovered"], most)
             if np.isfinite(lo) and lo < -3 * s:
                 assert st["n_uncovered"] == 0
-            else:
+            elif least > 0:
                 assert st["n_uncovered"] > 0
         with c.relax(x, 0, s, FORCE, k, s / 2000, s / 20) as t:
             assert t.step(True)["n_uncovered"] == 0          # unlimited by default

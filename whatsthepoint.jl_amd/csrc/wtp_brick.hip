@@ -403,8 +403,10 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
             if (CS) {
                 const float tnn = (0.9f * g.c) * (0.9f * g.c); // < provable radius (>= c - c/256); holds the nearest neighbour
                 const float tcs = spec.lim > tnn ? spec.lim : tnn;
-                cs_fail = !(spec.lim <= tau);
-                tau = tcs < tau ? tcs : tau;
+                // the support only has to lie inside the provable radius of THIS query (c .. 1.5 c depending
+                // on where it sits in its cell); the gamma cap that bounds the k-selection ring does not apply
+                cs_fail = !(spec.lim <= g2);
+                tau = tcs < g2 ? tcs : g2;
             }
             // CS scan filter: d2 with fused multiply-adds (3 VALU instead of 5) against a threshold
             // 4 ulp wider.  The ring pass below recomputes the canonical d2 of every survivor and

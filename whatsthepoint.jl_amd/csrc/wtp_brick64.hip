@@ -71,7 +71,6 @@ __global__ __launch_bounds__(kB64Threads, 2) void brick_cs_kernel(SearchArgs<T> 
     uint16_t* ring = ring_all + tid; // entry j at ring[j * kB64Threads]; row kB64Ring is the dump row
     const Grid<T> g = *a.grid;
     const int K = a.k;
-    const T cap2 = (a.gamma_cap * g.c) * (a.gamma_cap * g.c);
     Acc acc = acc_empty();
     for (int j = 0; j <= kB64Ring; ++j) ring[j * kB64Threads] = 0; // masked reads use row 0: keep it a valid index
     if (tid < kB64SU) { // padding past the staged points: finite coordinates, never taken (masked by index)
@@ -197,8 +196,8 @@ __global__ __launch_bounds__(kB64Threads, 2) void brick_cs_kernel(SearchArgs<T> 
             const T g2 = safe_radius2(g, qp.x, qp.y, qp.z, cx, cy, cz, 1);
             const T s = a.spacing_pp ? a.spacing_pp[qid] : a.spacing_const;
             const T lim = (a.u0 * a.u0) * (s * s);
-            T tau = g2 < cap2 ? g2 : cap2;
-            const bool cs_fail = !(lim <= tau);           // the 27 cells do not certify the support
+            T tau = g2;
+            const bool cs_fail = !(lim <= g2);            // the 27 cells do not certify the support
             const T tnn = ((T)0.9 * g.c) * ((T)0.9 * g.c); // margin that (almost) always holds the nearest neighbour
             const T tcs = lim > tnn ? lim : tnn;
             tau = tcs < tau ? tcs : tau;

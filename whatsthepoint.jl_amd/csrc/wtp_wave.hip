@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
         // u0*s holds 2..k points (self included) they ARE the nearest ones, the nearest neighbour is among
         // them and the sum over them is the reference's sum (adding zeros changes nothing).  That ball
         // needs a much smaller block than the k-th neighbour and no selection at all.  Anything else
-        // (empty ball, more than k points, list overflow) takes the general path below.
+        // (more than k points, list overflow) takes the general path below.
         int Kq = K;            // neighbours emitted: K, or the ball's population on the shortcut
         T cs_lim = (T)0;
         int cs_r = 0;
@@ -189,11 +189,15 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
                     cs_done = true;
                     break;
                 }
+                // Alone in its support ball: every term of the sum is exactly 0 and only the nearest
+                // neighbour (nn_dist / nn_id) is still unknown — a 2-nearest search (self + one) gives
+                // the same step as the k-list would, for a fraction of the block and no real selection.
+                if (!overflow && m == 1) Kq = 2;
                 overflow = false;
                 continue; // general path
             }
             if (overflow) break;
-            if (m >= K) break;                       // everything inside g2 is known: the k-th is final
+            if (m >= Kq) break;                      // everything inside g2 is known: the Kq-th is final
             if (g2 == Lim<T>::inf()) break;          // block covers the grid
             r2 *= 2;
         }
@@ -327,7 +331,9 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
                 a.nn_id[slot] = nid;
                 acc_point(acc, (double)f, (double)nd, (double)s, id, nid);
                 // sharded sessions: what the answer rests on — the k-th neighbour, or the support ball
-                if (reaches_past_cover<T>(a, q.x, q.y, q.z, cs_done ? cs_lim : sm->od2[K - 1])) atomicAdd(a.uncovered, 1);
+                const T last = sm->od2[Kq - 1];
+                const T need = cs_done ? cs_lim : (Kq < K ? (last > cs_lim ? last : cs_lim) : last);
+                if (reaches_past_cover<T>(a, q.x, q.y, q.z, need)) atomicAdd(a.uncovered, 1);
             }
         }
         __builtin_amdgcn_wave_barrier();
