@@ -260,8 +260,11 @@ typedef struct FN(kdq) {
     int32_t* bi;
 } FN(kdq);
 
-/* lower bounds are formed in long double so rounding can never prune a candidate whose
- * REAL-evaluated d2 would have been accepted */
+/* Lower bounds are formed in long double, i.e. (nearly) exactly — but a candidate's d2 is evaluated
+ * in REAL and may round BELOW its exact value by a few ulp.  On inputs full of exact ties
+ * (lattices) an exact bound therefore pruned subtrees holding points whose REAL d2 ties or beats
+ * the current k-th.  The bound is relaxed by 8 REAL ulps before it is compared. */
+#define KD_SLACK (1.0L - 8.0L * (long double)REAL_EPS)
 static void FN(kd_search)(FN(kdq)* s, int32_t node, long double lb, long double off[3]) {
     const FN(kdtree)* t = s->t;
     const FN(kdnode)* nd = &t->nodes[node];
@@ -293,8 +296,7 @@ static void FN(kd_search)(FN(kdq)* s, int32_t node, long double lb, long double 
     long double nlb = lb - old * old + diff * diff;
     if (fabsl(diff) < fabsl(old)) nlb = lb; /* never tighten below the accumulated bound */
     off[sd] = fabsl(diff) > fabsl(old) ? diff : old;
-    /* conservative slack: one part in 2^40 */
-    FN(kd_search)(s, far, nlb * (1.0L - 0x1p-40L), off);
+    FN(kd_search)(s, far, nlb * KD_SLACK, off);
     off[sd] = old;
 }
 
@@ -317,7 +319,7 @@ static void FN(kd_knn)(const FN(kdtree)* t, const REAL* q, int k, int32_t skip, 
         off[d] = o;
         lb += o * o;
     }
-    FN(kd_search)(&s, 0, lb * (1.0L - 0x1p-40L), off);
+    FN(kd_search)(&s, 0, lb * KD_SLACK, off);
     *m_out = s.m;
 }
 
@@ -384,7 +386,7 @@ static void FN(kd_range)(const FN(kdtree)* t, int32_t node, const REAL* q, REAL 
     long double nlb = lb - old * old + diff * diff;
     if (fabsl(diff) < fabsl(old)) nlb = lb;
     off[sd] = fabsl(diff) > fabsl(old) ? diff : old;
-    FN(kd_range)(t, far, q, r2, skip, nlb * (1.0L - 0x1p-40L), off, row, rd, m, cap);
+    FN(kd_range)(t, far, q, r2, skip, nlb * KD_SLACK, off, row, rd, m, cap);
     off[sd] = old;
 }
 
@@ -734,6 +736,7 @@ void FN(wtpo_isinside_winding)(const REAL* test, int64_t n, const REAL* poly, in
 }
 
 #undef KD_LEAF
+#undef KD_SLACK
 #undef FN
 #undef CAT
 #undef CAT_

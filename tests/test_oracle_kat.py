@@ -164,3 +164,20 @@ def test_generator_three_implementations_agree(O, wtp):
     a = wtp.synth.uniform(5000, 3, np.float32, 20260821, first=17)
     b = O.gen_uniform(20260821, 5000, 3, np.float32, first=17)
     assert np.array_equal(a, b) and a.min() >= 0 and a.max() < 1
+
+
+@pytest.mark.parametrize("m,dim,k,dtype", [(7, 3, 21, np.float32), (45, 2, 21, np.float32), (173, 2, 12, np.float32),
+                                           (12, 3, 21, np.float64), (30, 2, 5, np.float64)])
+def test_kdtree_equals_brute_force_on_exact_lattices(O, m, dim, k, dtype):
+    """All-ties inputs: a candidate's d2, evaluated in T, may round below the exact bound of the
+    subtree that holds it, so the kd-tree's pruning bound carries a few ulp of slack (found by
+    tools/fuzz_parity.py: the exact bound dropped tying candidates on lattices)."""
+    g = np.stack(np.meshgrid(*[np.arange(m)] * dim, indexing="ij"), -1).reshape(-1, dim) / m
+    x = g.astype(dtype)
+    ik, dk = O.knn(x, k)
+    ib, db = O.knn(x, k, False, "brute")
+    assert np.array_equal(ik, ib) and np.array_equal(dk, db)
+    r = float(np.median(db[:, min(k - 1, 5)]))
+    ok, rk = O.radius(x, r)
+    ob, rb = O.radius(x, r, "brute")
+    assert np.array_equal(ok, ob) and np.array_equal(rk, rb)
