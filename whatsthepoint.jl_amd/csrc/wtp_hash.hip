@@ -304,8 +304,8 @@ template <> struct CanonCap<float> { static constexpr int pts = 3072; };   // 48
 template <> struct CanonCap<double> { static constexpr int pts = 1536; };
 
 // A workgroup owns kThreads consecutive cells = one contiguous run of the sorted array.  The run
-// is staged into LDS with coalesced loads, each thread insertion-sorts its own cell by id there,
-// and the run is written back coalesced.  Runs too large for LDS sort in place in global memory.
+// is staged into LDS with coalesced loads, each thread insertion-sorts its own cell by id there and
+// writes it back if anything moved.  Runs too large for LDS sort in place in global memory.
 template <typename T>
 __global__ __launch_bounds__(kThreads) void canon_kernel(Pt<T>* __restrict__ pts,
                                                          const int32_t* __restrict__ cell_start,
@@ -330,16 +330,24 @@ __global__ __launch_bounds__(kThreads) void canon_kernel(Pt<T>* __restrict__ pts
         if (m >= 2 && m <= kCanonMax) {
             if (in_lds) {
                 Pt<T>* b = buf + (s - p0);
+                bool moved = false;
                 for (int i = 1; i < m; ++i) {
+                    const int kid = w_to_id(b[i].w);
+                    if (w_to_id(b[i - 1].w) <= kid) continue; // in place already: one 4-byte compare
                     const Pt<T> key = b[i];
-                    const int kid = w_to_id(key.w);
                     int j = i - 1;
                     while (j >= 0 && w_to_id(b[j].w) > kid) {
                         b[j + 1] = b[j];
                         --j;
                     }
                     b[j + 1] = key;
+                    moved = true;
                 }
+                // On rebuilds the input is the previous canonical order and a run of same-cell points
+                // keeps its order through the ranking, so nearly every cell arrives sorted: only the
+                // cells that really changed are written back (the pass is read-only otherwise).
+                if (moved)
+                    for (int i = 0; i < m; ++i) pts[s + i] = b[i];
             } else {
                 for (int i = 1; i < m; ++i) {
                     const Pt<T> key = pts[s + i];
@@ -352,10 +360,6 @@ __global__ __launch_bounds__(kThreads) void canon_kernel(Pt<T>* __restrict__ pts
                     pts[s + j + 1] = key;
                 }
             }
-        }
-        if (in_lds) {
-            __syncthreads();
-            for (int i = p0 + threadIdx.x; i < p1; i += kThreads) pts[i] = buf[i - p0];
         }
     }
 }
