@@ -1,0 +1,44 @@
+"""Clouds whose bounding box is stretched by a few far outliers: the hash lays its grid over the
+bulk (quantile box) and clamps the rest into the edge cells; results must stay exact and the run
+must not degrade to the quadratic regime."""
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cloud(wtp, n, dtype, far):
+    x = wtp.synth.uniform(n, 3, dtype, 23)
+    x[:5] = np.array([[far, 0.3, 0.3], [-far, 0.7, 0.2], [0.5, far, 0.5], [0.2, 0.2, -far], [far, far, far]], dtype=dtype)
+    return x
+
+
+@pytest.mark.parametrize("dtype,far", [(np.float32, 3e3), (np.float32, 1e7), (np.float64, 1e9)])
+def test_knn_with_far_outliers_is_exact_and_fast(O, wtp, ctx, dtype, far):
+    n = 60000
+    x = _cloud(wtp, n, dtype, far)
+    ctx.knn(x[:2000], 8)                                     # warm the context up
+    t0 = time.perf_counter()
+    idx, dist = ctx.knn(x, 21, return_dist=True)
+    dt = time.perf_counter() - t0
+    widx, wdist = O.knn(x, 21)
+    assert np.array_equal(idx, widx) and np.array_equal(dist, wdist)
+    assert dt < 0.5, dt                                      # the degenerate grid took seconds here
+
+
+def test_sweep_with_far_outliers_matches_oracle(O, wtp, ctx):
+    n = 40000
+    x = _cloud(wtp, n, np.float32, 1e6)
+    s = float(n) ** (-1.0 / 3.0)
+    with ctx.relax(x, 0, s, dict(kind=2, beta=0.2, u0=1.0, gamma=3.0), 21, s / 2000, s / 20) as t:
+        st = t.step(True)
+        got = t.positions()
+        pd = t.point_data()
+    r = O.relax_sweep(x, 0, s, 2, 0.2, 1.0, 3.0, 21, s / 2000, s / 20)
+    err = np.abs(got[5:] - r["p"][5:]).max() / s
+    assert err < 1e-4                                         # bulk: fp32 tolerance at coordinates ~1
+    assert np.array_equal(got[:5], r["p"][:5])               # the outliers feel no force and stay put
+    assert np.array_equal(pd["nn_id"], r["nn_id"])
+    assert st["n_move"] == n

@@ -140,6 +140,61 @@ static double hash_target_rho(const wtp_ctx* ctx, int dim, int k, double radius,
     return r < 1.0 ? 1.0 : r;
 }
 
+// Quantile box: when a few far outliers stretch the bounding box so much that even the finest grid
+// the caps allow (4096 cells per axis, 8 n cells) leaves the bulk of the cloud in a handful of cells,
+// the grid is laid over the bulk only.  Per-axis histograms are zoomed (<= 4 rounds of 1024 bins)
+// onto the range that holds all but 0.05 % of the points on either side; points outside are clamped
+// into the edge cells, which every search treats as unbounded outward — results stay exact.
+template <typename T>
+static int find_robust_box(wtp_ctx* ctx, const Pt<T>* in, int64_t n, int dim, const Grid<T>& hg) {
+    int rc;
+    const size_t hist_bytes = sizeof(unsigned int) * 3 * 1024;
+    if ((rc = ensure(ctx, ctx->box_dev, 64 + hist_bytes))) return rc;
+    if ((rc = ensure_pinned(ctx, 64 + hist_bytes))) return rc;
+    double box[6];
+    for (int a = 0; a < 3; ++a) {
+        box[a] = (double)hg.org[a];
+        box[3 + a] = (double)hg.org[a] + (double)hg.n[a] * (double)hg.c;
+    }
+    const uint64_t tail = (uint64_t)(n / 2000) + 1; // 0.05 % per side
+    for (int round = 0; round < 4; ++round) {
+        memcpy(ctx->host_pinned, box, sizeof(box));
+        WTP_HIP(ctx, hipMemcpyAsync(ctx->box_dev.p, ctx->host_pinned, sizeof(box), hipMemcpyHostToDevice, ctx->stream));
+        unsigned int* d_hist = (unsigned int*)((char*)ctx->box_dev.p + 64);
+        if ((rc = launch_axis_hist<T>(ctx, in, n, dim, (const double*)ctx->box_dev.p, d_hist))) return rc;
+        WTP_HIP(ctx, hipMemcpyAsync((char*)ctx->host_pinned + 64, d_hist, hist_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        if ((rc = sync(ctx))) return rc;
+        const unsigned int* h = (const unsigned int*)((const char*)ctx->host_pinned + 64);
+        bool shrunk = false;
+        for (int a = 0; a < dim; ++a) {
+            const double w = (box[3 + a] - box[a]) / 1024.0;
+            if (!(w > 0)) continue;
+            uint64_t run = 0;
+            int b_lo = 0, b_hi = 1023;
+            for (int b = 0; b < 1024; ++b) {
+                run += h[a * 1024 + b];
+                if (run >= tail) { b_lo = b; break; }
+            }
+            run = 0;
+            for (int b = 1023; b >= 0; --b) {
+                run += h[a * 1024 + b];
+                if (run >= tail) { b_hi = b; break; }
+            }
+            if (b_hi < b_lo) b_hi = b_lo;
+            const double nlo = box[a] + w * b_lo, nhi = box[a] + w * (b_hi + 1);
+            if ((nhi - nlo) < 0.5 * (box[3 + a] - box[a])) shrunk = true;
+            box[a] = nlo;
+            box[3 + a] = nhi;
+        }
+        if (!shrunk) break;
+    }
+    memcpy(ctx->host_pinned, box, sizeof(box));
+    WTP_HIP(ctx, hipMemcpyAsync(ctx->box_dev.p, ctx->host_pinned, sizeof(box), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = sync(ctx))) return rc;
+    ctx->box_active = true;
+    return WTP_OK;
+}
+
 template <typename T>
 static int build_hash_tuned(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, int k, double radius,
                             double rho_direct, double min_cell, double* scale_io, double* rho_eff_out, Grid<T>* hg_out) {
@@ -148,7 +203,9 @@ static int build_hash_tuned(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n
     double prev_c = -1;
     int rc;
     if ((rc = ensure(ctx, ctx->occ, 64))) return rc;
-    if ((rc = ensure_pinned(ctx, 1024))) return rc;
+    if ((rc = ensure_pinned(ctx, 16384))) return rc;
+    ctx->box_active = false; // every tuned build starts from the true bounding box
+    bool boxed = false;
     for (int round = 0; round < 3; ++round) {
         if ((rc = build_hash<T>(ctx, in, out, n, dim, k, radius, rho_direct, min_cell, scale))) return rc;
         if ((rc = launch_occupancy(ctx, (unsigned long long*)ctx->occ.p))) return rc;
@@ -163,6 +220,18 @@ static int build_hash_tuned(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n
         *rho_eff_out = rho_eff;
         *hg_out = hg;
         const double excess = (rho_eff - 1.0) / target;
+        // the caps on the cell count bind (4096 per axis / 8 n) and the cells are still far over-full:
+        // the box is stretched by outliers — lay the grid over the bulk and start over, once
+        const bool capped = hg.n[0] >= kMaxAxisCells || hg.n[1] >= kMaxAxisCells || hg.n[2] >= kMaxAxisCells ||
+                            (double)hg.ncells > 6.0 * (double)n;
+        if (excess > 4.0 && capped && !boxed && radius <= 0) {
+            if ((rc = find_robust_box<T>(ctx, in, n, dim, hg))) return rc;
+            boxed = true;
+            scale = 1.0;
+            prev_c = -1;
+            round = -1;
+            continue;
+        }
         if (!(excess > 1.6) || round == 2) break;
         if (prev_c > 0 && !((double)hg.c < prev_c * 0.999)) break; // a floor binds: shrinking changes nothing
         prev_c = (double)hg.c;
@@ -194,7 +263,8 @@ static int knn_dev_t(wtp_ctx* ctx, const T* d_xyz, int64_t n, int dim, int k, in
     // The measured cell scale of the last topology call is reused for a cloud of the same size (the
     // usual case: rebuild_topology! on the same points); it only affects speed, never the result.
     const int kq = include_self ? k : k + 1;
-    if (ctx->knn_tune_n == n && ctx->knn_tune_dim == dim && ctx->knn_tune_k == kq) {
+    if (ctx->knn_tune_n == n && ctx->knn_tune_dim == dim && ctx->knn_tune_k == kq && !ctx->knn_tune_boxed) {
+        ctx->box_active = false;
         if ((rc = build_hash<T>(ctx, raw, sorted, n, dim, kq, 0.0, 0.0, 0.0, ctx->knn_tune_scale))) return rc;
     } else {
         double scale = 1.0, rho_eff = 0;
@@ -204,6 +274,7 @@ static int knn_dev_t(wtp_ctx* ctx, const T* d_xyz, int64_t n, int dim, int k, in
         ctx->knn_tune_dim = dim;
         ctx->knn_tune_k = kq;
         ctx->knn_tune_scale = scale;
+        ctx->knn_tune_boxed = ctx->box_active; // a clipped box belongs to this very cloud: never reuse it
     }
     span_end(ctx, sp);
     SearchArgs<T> a{};
@@ -300,7 +371,7 @@ WTP_API int wtp_destroy(wtp_ctx* ctx) {
                       &ctx->idx_out, &ctx->dist_out, &ctx->counts_out, &ctx->forces, &ctx->nn_dist,
                       &ctx->nn_id, &ctx->spacing_pp, &ctx->partials, &ctx->stats, &ctx->fb_list,
                       &ctx->fb_count, &ctx->fb2_list, &ctx->fb2_count, &ctx->scratch, &ctx->diag,
-                      &ctx->ins_in, &ctx->ins_elems, &ctx->ins_partial, &ctx->ins_out, &ctx->kd_nodes, &ctx->sp_hint, &ctx->occ};
+                      &ctx->ins_in, &ctx->ins_elems, &ctx->ins_partial, &ctx->ins_out, &ctx->kd_nodes, &ctx->sp_hint, &ctx->occ, &ctx->box_dev};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     if (ctx->host_pinned) hipHostFree(ctx->host_pinned);
@@ -363,6 +434,7 @@ template <typename T> static int radius_count_t(wtp_ctx* ctx, int64_t n, int dim
     Pt<T>* sorted = (Pt<T>*)ctx->pts[1].p;
     int sp = span_begin(ctx, 0);
     if ((rc = load_points<T>(ctx, (const T*)ctx->raw_in.p, raw, n, dim))) return rc;
+    ctx->box_active = false;
     if ((rc = build_hash<T>(ctx, raw, sorted, n, dim, 0, r > 0 ? r : 1e-300))) return rc;
     span_end(ctx, sp);
     SearchArgs<T> a{};

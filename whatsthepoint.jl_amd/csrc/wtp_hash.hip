@@ -80,7 +80,7 @@ __global__ void bbox_kernel(const Pt<T>* __restrict__ pts, int64_t n, T* __restr
 template <typename T>
 __global__ void grid_setup_kernel(const T* __restrict__ part, int nparts, Grid<T>* __restrict__ g,
                                   int64_t npts, int dim, double rho_k, double radius, double min_cell, int cell_cap,
-                                  double cell_scale) {
+                                  double cell_scale, const double* __restrict__ box) {
     // one wave: lanes stride over the per-block partials, shuffle-reduce, lane 0 does the setup
     double mn[3], mx[3];
     for (int a = 0; a < 3; ++a) {
@@ -97,6 +97,12 @@ __global__ void grid_setup_kernel(const T* __restrict__ part, int nparts, Grid<T
         }
         mn[a] = (double)lo;
         mx[a] = (double)hi;
+        // robust box (outliers): the grid covers the bulk only; whatever lies outside is clamped into
+        // the edge cells, which the search treats as unbounded outward
+        if (box) {
+            mn[a] = box[a] > mn[a] ? box[a] : mn[a];
+            mx[a] = box[3 + a] < mx[a] ? box[3 + a] : mx[a];
+        }
     }
     if (threadIdx.x != 0) return;
     double ext[3], emax = 0;
@@ -437,6 +443,45 @@ template <typename T> int launch_sum(wtp_ctx* ctx, const T* d_v, int64_t n, doub
     return WTP_OK;
 }
 
+// Per-axis histograms of the coordinates over [lo, hi] (1024 bins each): the host reads them to find
+// the quantile box of a cloud whose bounding box is stretched by outliers.
+static constexpr int kHistBins = 1024;
+
+template <typename T>
+__global__ void axis_hist_kernel(const Pt<T>* __restrict__ pts, int64_t n, int dim, const double* __restrict__ range,
+                                 unsigned int* __restrict__ hist) {
+    __shared__ unsigned int sh[3 * kHistBins];
+    for (int i = threadIdx.x; i < 3 * kHistBins; i += blockDim.x) sh[i] = 0;
+    __syncthreads();
+    double lo[3], scale[3];
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = range[a];
+        const double w = range[3 + a] - range[a];
+        scale[a] = w > 0 ? (double)kHistBins / w : 0.0;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const Pt<T> p = pts[i];
+        const double v[3] = {(double)p.x, (double)p.y, (double)p.z};
+        for (int a = 0; a < dim; ++a) {
+            double f = (v[a] - lo[a]) * scale[a];
+            int b = f > 0 ? (f < (double)(kHistBins - 1) ? (int)f : kHistBins - 1) : 0; // NaN -> 0
+            atomicAdd(&sh[a * kHistBins + b], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * kHistBins; i += blockDim.x)
+        if (sh[i]) atomicAdd(&hist[i], sh[i]);
+}
+
+template <typename T>
+int launch_axis_hist(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int dim, const double* d_range, unsigned int* d_hist) {
+    WTP_HIP(ctx, hipMemsetAsync(d_hist, 0, sizeof(unsigned int) * 3 * kHistBins, ctx->stream));
+    hipLaunchKernelGGL(axis_hist_kernel<T>, dim3(grid_for(n, kThreads, 512)), dim3(kThreads), 0, ctx->stream, pts, n, dim,
+                       d_range, d_hist);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
 int launch_occupancy(wtp_ctx* ctx, unsigned long long* d_out3) {
     WTP_HIP(ctx, hipMemsetAsync(d_out3, 0, 3 * sizeof(unsigned long long), ctx->stream));
     hipLaunchKernelGGL(occupancy_kernel, dim3(1024), dim3(kThreads), 0, ctx->stream, (const int32_t*)ctx->cell_cnt.p,
@@ -478,7 +523,7 @@ int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, in
     WTP_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)(cap + 1), st));
     hipLaunchKernelGGL(bbox_kernel<T>, dim3(nbb), dim3(kThreads), 0, st, in, n, part);
     hipLaunchKernelGGL(grid_setup_kernel<T>, dim3(1), dim3(64), 0, st, part, nbb, g, n, dim, rho_k, radius, min_cell, cap,
-                       cell_scale);
+                       cell_scale, ctx->box_active ? (const double*)ctx->box_dev.p : (const double*)nullptr);
     ctx->ncells_dev = &g->ncells;
     const int nb = grid_for(n, kThreads, 16384);
     hipLaunchKernelGGL(cell_rank_kernel<T>, dim3(nb), dim3(kThreads), 0, st, in, n, g, cnt, cr);
@@ -878,6 +923,7 @@ int launch_refix(wtp_ctx* ctx, const Pt<T>* in, int64_t n_old, int64_t n_fixed_o
 // explicit instantiations
 #define INST(T)                                                                                         \
     template int launch_sum<T>(wtp_ctx*, const T*, int64_t, double*);                                   \
+    template int launch_axis_hist<T>(wtp_ctx*, const Pt<T>*, int64_t, int, const double*, unsigned int*); \
     template int launch_layers<T>(wtp_ctx*, const Pt<T>*, int64_t, int64_t, int, double, double, double, double, \
                                   Pt<T>*, Pt<T>*, int64_t, int2*, int32_t*, bool, double);              \
     template int launch_refix<T>(wtp_ctx*, const Pt<T>*, int64_t, int64_t, int64_t, const Pt<T>*, Pt<T>*, int32_t*); \

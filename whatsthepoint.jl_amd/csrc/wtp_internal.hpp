@@ -170,11 +170,14 @@ struct wtp_ctx {
     int64_t knn_tune_n = -1;   // topology calls: cloud size / dim / k the cached cell scale was measured for
     int knn_tune_dim = 0, knn_tune_k = 0;
     double knn_tune_scale = 1.0;
+    bool knn_tune_boxed = false;
     // pooled device buffers
     wtp::DevBuf pts[3];        // Pt arrays
     wtp::DevBuf raw_in;        // AoS staging of host input
     wtp::DevBuf cell_of, rank_of, cell_cnt, cell_start, scan_tmp;
     wtp::DevBuf grid, bbox_part, occ;
+    wtp::DevBuf box_dev;       // robust box {lo xyz, hi xyz} (doubles) + histogram scratch behind it
+    bool box_active = false;   // grid_setup clips the bounding box to box_dev (outliers piled into edge cells)
     const void* ncells_dev = nullptr; // device address of Grid::ncells of the last build_hash
     wtp::DevBuf idx_out, dist_out, counts_out;
     wtp::DevBuf forces, nn_dist, nn_id, spacing_pp;
@@ -233,6 +236,9 @@ int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, in
 // occupancy of the grid the last build_hash made: d_out3 = [sum cnt^2, sum cnt, max cnt]
 int launch_occupancy(wtp_ctx* ctx, unsigned long long* d_out3);
 template <typename T> int launch_sum(wtp_ctx* ctx, const T* d_v, int64_t n, double* d_out);
+// per-axis coordinate histograms over d_range = {lo xyz, hi xyz}: 3 x 1024 bins
+template <typename T>
+int launch_axis_hist(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int dim, const double* d_range, unsigned int* d_hist);
 
 template <typename T>
 int load_points(wtp_ctx* ctx, const T* d_xyz, Pt<T>* out, int64_t n, int dim);
