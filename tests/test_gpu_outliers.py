@@ -42,3 +42,12 @@ def test_sweep_with_far_outliers_matches_oracle(O, wtp, ctx):
     assert np.array_equal(got[:5], r["p"][:5])               # the outliers feel no force and stay put
     assert np.array_equal(pd["nn_id"], r["nn_id"])
     assert st["n_move"] == n
+
+
+def test_non_finite_points_do_not_disturb_the_rest(O, wtp, ctx):
+    n = 20000
+    x = wtp.synth.uniform(n, 3, np.float32, 29)
+    bad = np.array([[np.nan, 0.5, 0.5], [0.5, np.inf, 0.5], [-np.inf, np.nan, 0.1]], dtype=np.float32)
+    idx, dist = ctx.knn(np.concatenate([x, bad]), 21, return_dist=True)
+    widx, wdist = O.knn(x, 21)
+    assert np.array_equal(idx[:n], widx) and np.array_equal(dist[:n], wdist)   # never closer than anything finite

@@ -39,6 +39,10 @@ __global__ void bbox_kernel(const Pt<T>* __restrict__ pts, int64_t n, T* __restr
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
         Pt<T> p = pts[i];
+        // non-finite coordinates (x - x != 0) do not shape the box; such points end up in edge cells
+        if (!(p.x - p.x == (T)0)) p.x = mn[0] < mx[0] ? mn[0] : (T)0;
+        if (!(p.y - p.y == (T)0)) p.y = mn[1] < mx[1] ? mn[1] : (T)0;
+        if (!(p.z - p.z == (T)0)) p.z = mn[2] < mx[2] ? mn[2] : (T)0;
         mn[0] = p.x < mn[0] ? p.x : mn[0];
         mx[0] = p.x > mx[0] ? p.x : mx[0];
         mn[1] = p.y < mn[1] ? p.y : mn[1];
