@@ -105,6 +105,20 @@ def other_paths(ctx, torch, np, wtp_amd):
                                        "tera_pairs_per_s": round(len(t) * len(ec) / dev / 1e12, 3),
                                        "inside_fraction": round(float(ins.mean()), 4),
                                        "note": "wtp_isinside_greens, host arrays in and out; VALU-bound (13 instr/pair)"}
+    # end to end: 1000 repel iterations on 10 M points, host array in -> host array out
+    # (PCIe both ways, session setup, all iterations, read-back), no stop rule firing (tol = 0)
+    ne = 10_000_000
+    xe = wtp_amd.synth.uniform(ne, 3, np.float32)
+    se = float(ne) ** (-1.0 / 3.0)
+    t0 = time.perf_counter()
+    with ctx.relax(xe, 0, se, dict(kind=2, beta=0.2, u0=1.0, gamma=3.0), 21, se / 2000, se / 20) as t:
+        conv, st = t.run(1000, 1)
+        pe = t.positions()
+    dt = time.perf_counter() - t0
+    out["repel_10M_1000_iters_end_to_end"] = {"value": round(dt, 3), "unit": "s", "Mpoints_per_s": round(ne * 1000 / dt / 1e6, 1),
+                                              "final_max_force": float(conv[-1]), "moved": bool(np.abs(pe - xe).max() > 0),
+                                              "note": "host array in, 1000 iterations (rebuild every step), host array out"}
+    del xe, pe
     # graded cloud (BASELINE config 5 / north star "uniform and graded clouds"): thinned uniform stream,
     # h_bulk/h_wall = 4, with its own BoundaryLayerSpacing law evaluated on the device
     ng = 1_000_000
