@@ -300,6 +300,99 @@ static int knn_dev_t(wtp_ctx* ctx, const T* d_xyz, int64_t n, int dim, int k, in
     return rc;
 }
 
+// fp64 clouds, KNNTopology: Float64 is the reference's default type, and the exact wave-per-query
+// path costs 16 ns per query.  Faster and still exact: search CANDIDATES in fp32 (the cloud moved to
+// its own origin and rounded to float; the k+2 nearest per query through the fp32 brick kernel),
+// re-rank them in exact fp64, and certify per query that nothing outside the candidate list can
+// belong to the answer (refine_f64_kernel).  Queries that fail the certificate — coincident
+// clusters larger than the list, clouds whose extent/spacing ratio exhausts float — take the exact
+// path.  Returns 1 in *done when it handled the call.
+static int knn_dev_f64(wtp_ctx* ctx, const double* d_xyz, int64_t n, int dim, int k, int include_self, int32_t* d_idx,
+                       double* d_dist, bool* done) {
+    *done = false;
+    const int kq = include_self ? k : k + 1;
+    // two candidates beyond the kq wanted: the certificate needs ONE whose fp32 distance clears the exact
+    // kq-th by more than the rounding bound (gaps between consecutive neighbour distances are ~1e-2 of
+    // the distance, the bound ~1e-6), and longer lists overflow the brick kernel's 64-entry ring
+    int kc = kq + 2;
+    if ((int64_t)kc > n) kc = (int)n;
+    if (ctx->force_generic || kc > 31) return WTP_OK; // beyond the fp32 brick kernel's list length: exact path
+    int rc;
+    if ((rc = ensure(ctx, ctx->pts[0], sizeof(double4) * (size_t)n))) return rc;
+    if ((rc = ensure(ctx, ctx->pts[1], sizeof(double4) * (size_t)n))) return rc;
+    if ((rc = ensure(ctx, ctx->f32_pts, 2 * sizeof(float4) * (size_t)n))) return rc;
+    if ((rc = ensure(ctx, ctx->cand_idx, sizeof(int32_t) * (size_t)n * kc))) return rc;
+    if ((rc = ensure(ctx, ctx->cand_dist, sizeof(float) * (size_t)n * kc))) return rc;
+    if ((rc = ensure(ctx, ctx->fb_list, sizeof(int32_t) * (size_t)n))) return rc;
+    if ((rc = ensure(ctx, ctx->fb_count, 64))) return rc;
+    if ((rc = ensure(ctx, ctx->fb2_list, sizeof(int32_t) * (size_t)n))) return rc;
+    if ((rc = ensure(ctx, ctx->fb2_count, 64))) return rc;
+    if ((rc = ensure(ctx, ctx->occ, 64))) return rc;
+    double4* raw64 = (double4*)ctx->pts[0].p;
+    float4* raw32 = (float4*)ctx->f32_pts.p;
+    float4* sorted32 = raw32 + n;
+    double* org4 = (double*)ctx->occ.p + 4; // behind the occupancy counters
+    int sp = span_begin(ctx, 0);
+    if ((rc = load_points<double>(ctx, d_xyz, raw64, n, dim))) return rc;
+    if ((rc = launch_origin(ctx, raw64, n, org4))) return rc;
+    if ((rc = launch_to_local_f32(ctx, raw64, n, org4, raw32))) return rc;
+    double scale = 1.0, rho_eff = 0;
+    Grid<float> hg;
+    if ((rc = build_hash_tuned<float>(ctx, raw32, sorted32, n, dim, kc, 0.0, 0.0, 0.0, &scale, &rho_eff, &hg))) return rc;
+    span_end(ctx, sp);
+    ctx->knn_tune_n = -1; // the cached scale belongs to fp32 calls
+    SearchArgs<float> a{};
+    a.grid = (const Grid<float>*)ctx->grid.p;
+    a.snap = sorted32;
+    a.query = sorted32;
+    a.cell_start = (const int32_t*)ctx->cell_start.p;
+    a.n = (int32_t)n;
+    a.k = kc;
+    a.include_self = 1;
+    a.idx_out = (int32_t*)ctx->cand_idx.p;
+    a.dist_out = (float*)ctx->cand_dist.p;
+    a.fb_list = (int32_t*)ctx->fb_list.p;
+    a.fb_count = (int32_t*)ctx->fb_count.p;
+    a.fb2_list = (int32_t*)ctx->fb2_list.p;
+    a.fb2_count = (int32_t*)ctx->fb2_count.p;
+    sp = span_begin(ctx, 1);
+    rc = launch_topology<float>(ctx, a);
+    if (rc) return rc;
+    rc = launch_refine_f64(ctx, raw64, a.idx_out, a.dist_out, n, kc, k, include_self, org4, d_idx, d_dist,
+                           (int32_t*)ctx->fb_list.p, (int32_t*)ctx->fb_count.p);
+    span_end(ctx, sp);
+    if (rc) return rc;
+    ctx->n_sweep_launches += 1;
+    ctx->relax.have_tree = false;
+    ctx->rad_valid = false;
+    if ((rc = ensure_pinned(ctx, 64))) return rc;
+    WTP_HIP(ctx, hipMemcpyAsync(ctx->host_pinned, ctx->fb_count.p, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = sync(ctx))) return rc;
+    const int32_t n_fail = *(const int32_t*)ctx->host_pinned;
+    if (n_fail > 0) { // exact fp64 path for the uncertified queries: wave kernel over their ids, fp64 grid
+        double4* sorted64 = (double4*)ctx->pts[1].p;
+        ctx->box_active = false;
+        if ((rc = build_hash<double>(ctx, raw64, sorted64, n, dim, kq, 0.0))) return rc;
+        SearchArgs<double> b{};
+        b.grid = (const Grid<double>*)ctx->grid.p;
+        b.snap = sorted64;
+        b.query = raw64; // list entries are ids: raw64[id] is the query, its w the id
+        b.cell_start = (const int32_t*)ctx->cell_start.p;
+        b.n = (int32_t)n;
+        b.k = k;
+        b.include_self = include_self;
+        b.idx_out = d_idx;
+        b.dist_out = d_dist;
+        b.fb_list = (int32_t*)ctx->fb_list.p;
+        b.fb_count = (int32_t*)ctx->fb_count.p;
+        b.fb2_list = (int32_t*)ctx->fb2_list.p;
+        b.fb2_count = (int32_t*)ctx->fb2_count.p;
+        if ((rc = launch_generic_topology<double>(ctx, b, false))) return rc;
+    }
+    *done = true;
+    return WTP_OK;
+}
+
 static int check_idle(wtp_ctx* ctx) {
     if (ctx->relax.active)
         return fail(ctx, WTP_ERR_STATE,
@@ -371,7 +464,8 @@ WTP_API int wtp_destroy(wtp_ctx* ctx) {
                       &ctx->idx_out, &ctx->dist_out, &ctx->counts_out, &ctx->forces, &ctx->nn_dist,
                       &ctx->nn_id, &ctx->spacing_pp, &ctx->partials, &ctx->stats, &ctx->fb_list,
                       &ctx->fb_count, &ctx->fb2_list, &ctx->fb2_count, &ctx->scratch, &ctx->diag,
-                      &ctx->ins_in, &ctx->ins_elems, &ctx->ins_partial, &ctx->ins_out, &ctx->kd_nodes, &ctx->sp_hint, &ctx->occ, &ctx->box_dev};
+                      &ctx->ins_in, &ctx->ins_elems, &ctx->ins_partial, &ctx->ins_out, &ctx->kd_nodes, &ctx->sp_hint, &ctx->occ, &ctx->box_dev,
+                      &ctx->cand_idx, &ctx->cand_dist, &ctx->f32_pts};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     if (ctx->host_pinned) hipHostFree(ctx->host_pinned);
@@ -389,10 +483,14 @@ WTP_API int wtp_knn_dev(wtp_ctx* ctx, const void* d_xyz, int64_t n, int dim, int
     if ((rc = check_idle(ctx))) return rc;
     if (!d_idx_out) return fail(ctx, WTP_ERR_ARG, "idx_out is NULL");
     WTP_HIP(ctx, hipSetDevice(ctx->device));
-    if (dtype == WTP_F32)
+    if (dtype == WTP_F32) {
         rc = knn_dev_t<float>(ctx, (const float*)d_xyz, n, dim, k, include_self, d_idx_out, (float*)d_dist_out);
-    else
-        rc = knn_dev_t<double>(ctx, (const double*)d_xyz, n, dim, k, include_self, d_idx_out, (double*)d_dist_out);
+    } else {
+        bool done = false;
+        rc = knn_dev_f64(ctx, (const double*)d_xyz, n, dim, k, include_self, d_idx_out, (double*)d_dist_out, &done);
+        if (!rc && !done)
+            rc = knn_dev_t<double>(ctx, (const double*)d_xyz, n, dim, k, include_self, d_idx_out, (double*)d_dist_out);
+    }
     if (rc) return rc;
     return sync(ctx);
 }
@@ -414,9 +512,14 @@ WTP_API int wtp_knn(wtp_ctx* ctx, const void* xyz, int64_t n, int dim, int dtype
     if (dtype == WTP_F32)
         rc = knn_dev_t<float>(ctx, (const float*)ctx->raw_in.p, n, dim, k, include_self, (int32_t*)ctx->idx_out.p,
                               (float*)ddist);
-    else
-        rc = knn_dev_t<double>(ctx, (const double*)ctx->raw_in.p, n, dim, k, include_self,
-                               (int32_t*)ctx->idx_out.p, (double*)ddist);
+    else {
+        bool done = false;
+        rc = knn_dev_f64(ctx, (const double*)ctx->raw_in.p, n, dim, k, include_self, (int32_t*)ctx->idx_out.p,
+                         (double*)ddist, &done);
+        if (!rc && !done)
+            rc = knn_dev_t<double>(ctx, (const double*)ctx->raw_in.p, n, dim, k, include_self,
+                                   (int32_t*)ctx->idx_out.p, (double*)ddist);
+    }
     if (rc) return rc;
     WTP_HIP(ctx, hipMemcpyAsync(idx_out, ctx->idx_out.p, sizeof(int32_t) * (size_t)n * k, hipMemcpyDeviceToHost,
                                 ctx->stream));

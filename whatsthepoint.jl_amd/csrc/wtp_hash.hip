@@ -447,6 +447,128 @@ template <typename T> int launch_sum(wtp_ctx* ctx, const T* d_v, int64_t n, doub
     return WTP_OK;
 }
 
+// ---- fp64 topology through an fp32 candidate search (wtp_api.hip knn_dev_f64) -------------------------
+// origin_kernel: bbox partials -> {min x, min y, min z, largest extent};  to_local_f32: double
+// points minus that origin, rounded to float, ids kept;  refine: exact fp64 re-ranking of the fp32
+// candidate lists with a certificate that no excluded point can belong to the answer.
+__global__ void origin_kernel(const double* __restrict__ part, int nparts, double* __restrict__ out4) {
+    double mn[3], mx[3];
+    for (int a = 0; a < 3; ++a) {
+        double lo = Lim<double>::inf(), hi = -Lim<double>::inf();
+        for (int b = threadIdx.x; b < nparts; b += 64) {
+            lo = part[b * 6 + a] < lo ? part[b * 6 + a] : lo;
+            hi = part[b * 6 + 3 + a] > hi ? part[b * 6 + 3 + a] : hi;
+        }
+        for (int d = 32; d >= 1; d >>= 1) {
+            double o = __shfl_down(lo, d, 64);
+            lo = o < lo ? o : lo;
+            o = __shfl_down(hi, d, 64);
+            hi = o > hi ? o : hi;
+        }
+        mn[a] = lo;
+        mx[a] = hi;
+    }
+    if (threadIdx.x == 0) {
+        double ext = 0;
+        for (int a = 0; a < 3; ++a) {
+            const double e = mx[a] - mn[a];
+            out4[a] = mn[a] == mn[a] && mn[a] > -Lim<double>::inf() && mn[a] < Lim<double>::inf() ? mn[a] : 0.0;
+            if (e == e && e > ext && e < Lim<double>::inf()) ext = e;
+        }
+        out4[3] = ext;
+    }
+}
+
+__global__ void to_local_f32_kernel(const double4* __restrict__ in, int64_t n, const double* __restrict__ org4,
+                                    float4* __restrict__ out) {
+    const double ox = org4[0], oy = org4[1], oz = org4[2];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double4 p = in[i];
+        float4 o;
+        o.x = (float)(p.x - ox);
+        o.y = (float)(p.y - oy);
+        o.z = (float)(p.z - oz);
+        o.w = id_to_w(0.f, w_to_id(p.w));
+        out[i] = o;
+    }
+}
+
+static constexpr int kRefineMax = 32;
+
+// One thread per query: exact d2 to its kc fp32 candidates (self among them), canonical order, first k.
+// Certificate: every point the fp32 search excluded is at least as far, in fp32-local arithmetic, as its
+// last candidate (distance dmax32); rounding the coordinates to float and evaluating in float moves a
+// distance by less than eps = extent 2^-21 + dmax32 2^-20, so an excluded point's exact distance exceeds
+// dmax32 - eps.  If the exact kq-th candidate distance is strictly below that, the first kq candidates
+// in exact order are the answer; otherwise the query goes to the exact fp64 path.
+__global__ void refine_f64_kernel(const double4* __restrict__ raw, const int32_t* __restrict__ cand,
+                                  const float* __restrict__ cdist, int64_t n, int kc, int k, int include_self,
+                                  const double* __restrict__ org4, int32_t* __restrict__ idx_out,
+                                  double* __restrict__ dist_out, int32_t* __restrict__ fail_list,
+                                  int32_t* __restrict__ fail_count) {
+    const double extent = org4[3];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double4 q = raw[i];
+        double kd[kRefineMax];
+        int32_t ki[kRefineMax];
+        int m = 0;
+        for (int j = 0; j < kc; ++j) {
+            const int32_t c = cand[i * kc + j];
+            const double4 p = raw[c];
+            const double d = dist2<double>(q.x, q.y, q.z, p.x, p.y, p.z);
+            int pos = m++;
+            while (pos > 0 && lex_lt(d, c, kd[pos - 1], ki[pos - 1])) {
+                kd[pos] = kd[pos - 1];
+                ki[pos] = ki[pos - 1];
+                --pos;
+            }
+            kd[pos] = d;
+            ki[pos] = c;
+        }
+        const int kq = include_self ? k : k + 1;
+        const double dmax32 = (double)cdist[i * kc + kc - 1];
+        const double eps = extent * 0x1p-21 + dmax32 * 0x1p-20;
+        const bool certified = (int64_t)kc >= n || wsqrt(kd[kq - 1]) < dmax32 - eps;
+        int out = 0;
+        for (int j = 0; j < kc && out < k; ++j) {
+            if (!include_self && ki[j] == (int32_t)i) continue; // self removed by index (src/topology.jl:82)
+            idx_out[i * k + out] = ki[j];
+            if (dist_out) dist_out[i * k + out] = wsqrt(kd[j]);
+            ++out;
+        }
+        if (!certified || out < k) {
+            const int pos = atomicAdd(fail_count, 1);
+            fail_list[pos] = (int32_t)i;
+        }
+    }
+}
+
+int launch_origin(wtp_ctx* ctx, const double4* pts, int64_t n, double* d_org4) {
+    const int nbb = grid_for(n, kThreads, 1024);
+    int rc;
+    if ((rc = ensure(ctx, ctx->bbox_part, sizeof(double) * 6 * 1024))) return rc;
+    hipLaunchKernelGGL(bbox_kernel<double>, dim3(nbb), dim3(kThreads), 0, ctx->stream, pts, n, (double*)ctx->bbox_part.p);
+    hipLaunchKernelGGL(origin_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double*)ctx->bbox_part.p, nbb, d_org4);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
+int launch_to_local_f32(wtp_ctx* ctx, const double4* in, int64_t n, const double* d_org4, float4* out) {
+    hipLaunchKernelGGL(to_local_f32_kernel, dim3(grid_for(n, kThreads, 8192)), dim3(kThreads), 0, ctx->stream, in, n, d_org4, out);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
+int launch_refine_f64(wtp_ctx* ctx, const double4* raw, const int32_t* cand, const float* cdist, int64_t n, int kc, int k,
+                      int include_self, const double* d_org4, int32_t* idx_out, double* dist_out, int32_t* fail_list,
+                      int32_t* fail_count) {
+    WTP_HIP(ctx, hipMemsetAsync(fail_count, 0, sizeof(int32_t), ctx->stream));
+    hipLaunchKernelGGL(refine_f64_kernel, dim3(grid_for(n, 128, 16384)), dim3(128), 0, ctx->stream, raw, cand, cdist, n, kc,
+                       k, include_self, d_org4, idx_out, dist_out, fail_list, fail_count);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
 // Per-axis histograms of the coordinates over [lo, hi] (1024 bins each): the host reads them to find
 // the quantile box of a cloud whose bounding box is stretched by outliers.
 static constexpr int kHistBins = 1024;

@@ -180,6 +180,7 @@ struct wtp_ctx {
     bool box_active = false;   // grid_setup clips the bounding box to box_dev (outliers piled into edge cells)
     const void* ncells_dev = nullptr; // device address of Grid::ncells of the last build_hash
     wtp::DevBuf idx_out, dist_out, counts_out;
+    wtp::DevBuf cand_idx, cand_dist, f32_pts; // fp64 topology: fp32 candidate lists and the float copy of the cloud
     wtp::DevBuf forces, nn_dist, nn_id, spacing_pp;
     wtp::DevBuf partials, stats, fb_list, fb_count, fb2_list, fb2_count;
     wtp::DevBuf scratch;       // misc (relax_get staging, radius rows)
@@ -283,6 +284,12 @@ int launch_spacing_eval(wtp_ctx* ctx, const T* d_xyz, int64_t n, int dim, const 
 template <typename T>
 int launch_spacing_session(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int64_t first_id, const void* d_nodes, int64_t m,
                            int kind, double p0, double p1, double p2, T* d_spacing_pp, int32_t* d_hint);
+// fp64 topology through an fp32 candidate search (wtp_hash.hip)
+int launch_origin(wtp_ctx* ctx, const double4* pts, int64_t n, double* d_org4);
+int launch_to_local_f32(wtp_ctx* ctx, const double4* in, int64_t n, const double* d_org4, float4* out);
+int launch_refine_f64(wtp_ctx* ctx, const double4* raw, const int32_t* cand, const float* cdist, int64_t n, int kc, int k,
+                      int include_self, const double* d_org4, int32_t* idx_out, double* dist_out, int32_t* fail_list,
+                      int32_t* fail_count);
 // isinside post-filter (wtp_inside.hip)
 int isinside_chunks(wtp_ctx* ctx, int64_t n, int64_t m, int points_per_block);
 int isinside_greens_ppb();
