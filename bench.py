@@ -45,7 +45,7 @@ def cpu_baseline(points: int, iters: int):
                 sample=f"{iters} repel iterations on {points} uniform fp32 points (kd-tree + OpenMP oracle, {dt:.1f} s)")
 
 
-def other_paths(ctx, torch, np, wtp_amd):
+def other_paths(ctx, torch, np, wtp_amd, extra_legs=False):
     """Secondary lines of SURVEY.md §8d, measured in the same run on the same GPU (N=1 only):
     KNNTopology k=21 at 1 M points (C2), RadiusTopology on 1 M points at a radius holding ~21
     neighbours, and the isinside filter of repel's tail.  Device-resident where the ABI allows."""
@@ -105,6 +105,11 @@ def other_paths(ctx, torch, np, wtp_amd):
                                        "tera_pairs_per_s": round(len(t) * len(ec) / dev / 1e12, 3),
                                        "inside_fraction": round(float(ins.mean()), 4),
                                        "note": "wtp_isinside_greens, host arrays in and out; VALU-bound (13 instr/pair)"}
+    if not extra_legs:
+        # The legs below launch the headline's own kernel (brick_kernel<1,0,1>) on other workloads; they are
+        # opt-in (--extra-legs) so that a rocprofv3 --stats summary of the default command averages that
+        # kernel over the headline's launches only.  profiles/ holds a run with them.
+        return out
     # end to end: 1000 repel iterations on 10 M points, host array in -> host array out
     # (PCIe both ways, session setup, all iterations, read-back), no stop rule firing (tol = 0)
     ne = 10_000_000
@@ -173,6 +178,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-full-select", action="store_true", help="skip the explicit k-selection leg")
     ap.add_argument("--no-other-paths", action="store_true", help="skip the k-NN / radius / isinside lines")
+    ap.add_argument("--extra-legs", action="store_true",
+                    help="also: 1000-iteration end-to-end repel at 10 M points, graded-cloud repel and radius lines")
     ap.add_argument("--cpu-points", type=int, default=4_000_000)
     ap.add_argument("--cpu-iters", type=int, default=6)
     args = ap.parse_args()
@@ -343,7 +350,7 @@ def main():
         if world == 1 and not args.no_other_paths:
             if not sess_closed:
                 sess.close()
-            out["other_paths"] = other_paths(ctx, torch, np, wtp_amd)
+            out["other_paths"] = other_paths(ctx, torch, np, wtp_amd, args.extra_legs)
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.cpu_points, args.cpu_iters)
         print(json.dumps(out), flush=True)
