@@ -45,7 +45,7 @@ constexpr int NB = 64;          // per-lane candidate ring / sorting-network wid
 constexpr int kFastKMax = 32;   // k >= this goes to the wave kernel
 constexpr int kOwnRows = BY * BZ;
 #ifndef WTP_LANE_ROWS
-#define WTP_LANE_ROWS 0 // CS sweep: 1 = every lane walks its 9 candidate rows at its own pace
+#define WTP_LANE_ROWS 2 // CS sweep: 0 = rows in lockstep, 1 = every lane walks its 9 rows at its own pace, 2 = ... its TRIMMED rows (default)
 #endif
 #ifndef WTP_SCAN_U
 #define WTP_SCAN_U 8
@@ -430,9 +430,89 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
             }
             uint32_t kth = 0, next = 0;
             int rbase_l = ((hz - 1) * HY + (hy - 1)) * HX + (hx - 1); // CS lane rows: hstart index of my row
+            bool lr_started = false; // CS trimmed lane rows: first entry vs resume after ring pressure
+            uint32_t lr_q[9] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}; // queued runs: start | end << 16 (byte offsets)
+            int lr_n = 0;
             for (;;) {
                 bool pressure = false;
-                if (CS && WTP_LANE_ROWS) {
+                if (CS && WTP_LANE_ROWS == 2) {
+                    // Per-lane rows WITH trimming: a row (dy, dz) of the neighbourhood lies at least
+                    // gy, gz away from the query along y and z (distance to its own cell's faces, less the
+                    // cell map's rounding margin), so only candidates within rem = tau - gy^2 - gz^2 along
+                    // x can pass the filter: the row is skipped when rem < 0, its first / last cell when
+                    // the query is farther than sqrt(rem) from the own cell's lower / upper x face.  On
+                    // average 17 of the 27 cells survive.  Every lane walks its own trimmed rows, so the
+                    // wave runs for max over lanes of the trimmed total.
+                    const float cxl = g.org[0] + (float)cx * g.c, cyl = g.org[1] + (float)cy * g.c,
+                                czl = g.org[2] + (float)cz * g.c;
+                    auto gap2 = [&](float d) {
+                        const float t = d - g.margin;
+                        return t > 0.f ? t * t : 0.f;
+                    };
+                    const float lx2 = gap2(qp.x - cxl), ux2 = gap2(cxl + g.c - qp.x);
+                    const float ly2 = gap2(qp.y - cyl), uy2 = gap2(cyl + g.c - qp.y);
+                    const float lz2 = gap2(qp.z - czl), uz2 = gap2(czl + g.c - qp.z);
+                    const int base0 = (hz * HY + hy) * HX + (hx - 1);
+                    // The trimmed runs of the 9 rows are worked out once, all LDS reads in flight together,
+                    // and queued (non-empty ones only) as packed byte offsets start | end << 16 in nine
+                    // registers; taking the next run is then a register shift, no memory in the scan loop.
+                    if (!lr_started) {
+                        lr_started = true;
+                        pa = ea = 0u;
+                        lr_n = 0;
+                        uint32_t st[9], en[9];
+#pragma unroll
+                        for (int r9 = 0; r9 < 9; ++r9) {
+                            const int dzr = r9 / 3, dyr = r9 % 3;
+                            const float gy2 = dyr == 0 ? ly2 : (dyr == 2 ? uy2 : 0.f);
+                            const float gz2 = dzr == 0 ? lz2 : (dzr == 2 ? uz2 : 0.f);
+                            const float rem = tau_s - gy2 - gz2;
+                            const int rb = base0 + (dzr - 1) * (HY * HX) + (dyr - 1) * HX;
+                            const int i0 = rb + (lx2 <= rem ? 0 : 1), i1 = rb + (ux2 <= rem ? 3 : 2);
+                            st[r9] = (uint32_t)sm->hstart[i0];
+                            en[r9] = rem < 0.f ? st[r9] : (uint32_t)sm->hstart[i1];
+                        }
+#pragma unroll
+                        for (int r9 = 0; r9 < 9; ++r9) {
+                            const bool put = en[r9] > st[r9];
+                            const uint32_t pk = (st[r9] * 16u) | ((en[r9] * 16u) << 16);
+#pragma unroll
+                            for (int u9 = 0; u9 < 9; ++u9) lr_q[u9] = (put && lr_n == u9) ? pk : lr_q[u9];
+                            lr_n += put ? 1 : 0;
+                        }
+                    }
+                    auto advance = [&]() {
+                        if (pa >= ea && lr_n > 0) {
+                            const uint32_t pk = lr_q[0];
+#pragma unroll
+                            for (int u9 = 0; u9 < 8; ++u9) lr_q[u9] = lr_q[u9 + 1];
+                            --lr_n;
+                            pa = pk & 0xFFFFu;
+                            ea = pk >> 16;
+                        }
+                    };
+                    advance();
+                    while (__any(pa < ea)) {
+                        if (__any(ra > full_b)) {
+                            pressure = true;
+                            break;
+                        }
+                        f4 c[SU];
+                        lds_read_group(c, lds_base + pa);
+#pragma unroll
+                        for (int u = 0; u < SU; ++u) {
+                            const float ex = qp.x - c[u].x, ey = qp.y - c[u].y, ez = qp.z - c[u].z;
+                            const float d = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
+                            const float tl = (pa + 16u * u < ea) ? tau_s : -1.f;
+                            const bool take = d <= tl;
+                            *reinterpret_cast<uint16_t*>(smem_raw + (take ? ra : dump_b)) = (uint16_t)(pa + 16u * u);
+                            ra += take ? (kBrickThreads * 2u) : 0u;
+                        }
+                        pa += 16u * SU;
+                        advance();
+                    }
+                    if (!pressure) row = 9;
+                } else if (CS && WTP_LANE_ROWS == 1) {
                     // Every lane advances to its next row as soon as its current one is exhausted,
                     // so the wave runs for max over lanes of (sum of row lengths) steps instead of
                     // sum over rows of (max over lanes).
