@@ -447,6 +447,7 @@ WTP_API int wtp_create(const int* device_ordinals, int n_dev, wtp_ctx** out) {
     ctx->stream = ctx->own_stream;
     if (const char* e = getenv("WTP_RHO")) ctx->rho = atof(e) > 0 ? atof(e) : ctx->rho;
     if (const char* e = getenv("WTP_GAMMA_CAP")) ctx->gamma_cap = atof(e) > 0 ? atof(e) : ctx->gamma_cap;
+    if (const char* e = getenv("WTP_TNN")) ctx->tnn_frac = atof(e) > 0 && atof(e) < 0.99 ? atof(e) : ctx->tnn_frac;
     if (const char* e = getenv("WTP_FORCE_GENERIC")) ctx->force_generic = atoi(e);
     if (const char* e = getenv("WTP_FULL_SELECT")) ctx->full_select = atoi(e);
     if (const char* e = getenv("WTP_STYP_SIGMA")) ctx->styp_sigma = atof(e);
@@ -887,6 +888,7 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
     if ((rc = ensure(ctx, ctx->diag, 128))) return rc;
     a.diag = (unsigned long long*)ctx->diag.p;
     a.brick_hcap = r.cs_sweep ? r.brick_hcap : 0;
+    a.tnn_frac = (T)ctx->tnn_frac;
     a.cover_axis = r.cover_axis;
     a.cover_lo = (T)r.cover_lo;
     a.cover_hi = (T)r.cover_hi;

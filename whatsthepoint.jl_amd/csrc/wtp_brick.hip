@@ -401,7 +401,7 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
             // searched cells, go to the exact path.
             bool cs_fail = false;
             if (CS) {
-                const float tnn = (0.9f * g.c) * (0.9f * g.c); // < provable radius (>= c - c/256); holds the nearest neighbour
+                const float tnn = (a.tnn_frac * g.c) * (a.tnn_frac * g.c); // < provable radius (>= c - c/256); holds the nearest neighbour
                 const float tcs = spec.lim > tnn ? spec.lim : tnn;
                 // the support only has to lie inside the provable radius of THIS query (c .. 1.5 c depending
                 // on where it sits in its cell); the gamma cap that bounds the k-selection ring does not apply

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(kB64Threads, 2) void brick_cs_kernel(SearchArgs<T> 
             const T lim = (a.u0 * a.u0) * (s * s);
             T tau = g2;
             const bool cs_fail = !(lim <= g2);            // the 27 cells do not certify the support
-            const T tnn = ((T)0.9 * g.c) * ((T)0.9 * g.c); // margin that (almost) always holds the nearest neighbour
+            const T tnn = (a.tnn_frac * g.c) * (a.tnn_frac * g.c); // margin that (almost) always holds the nearest neighbour
             const T tcs = lim > tnn ? lim : tnn;
             tau = tcs < tau ? tcs : tau;
             T tau_s = tau * WideEps<T>::v;

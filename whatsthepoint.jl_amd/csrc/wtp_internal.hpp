@@ -118,6 +118,7 @@ template <typename T> struct SearchArgs {
     int32_t* uncovered;
     // tunables
     T gamma_cap;               // initial filter radius cap, in cell edges
+    T tnn_frac;                // CS sweeps: nearest-neighbour margin of the ring, in cell edges (WTP_TNN, default 0.8)
     int32_t brick_hcap;        // LDS point capacity for the brick kernel (0 = default)
     unsigned long long* diag;  // -DWTP_DIAG builds: per-phase wave-cycle sums (8 slots), else unused
 };
@@ -164,6 +165,7 @@ struct wtp_ctx {
     // tunables (env WTP_RHO / WTP_GAMMA_CAP / WTP_FORCE_GENERIC)
     double rho = 8.0;
     double gamma_cap = 1.08;
+    double tnn_frac = 0.8;     // WTP_TNN: measured optimum between candidate volume and isolated-query hand-backs (0.9: 1.55 ms, 0.8: 1.44, 0.7: 1.69 per 10 M step)
     int force_generic = 0;
     int full_select = 0;       // WTP_FULL_SELECT=1: never use the compact-support sweep
     double styp_sigma = 0.0;   // WTP_STYP_SIGMA: typical spacing = mean + this many standard deviations (measured: > 0 only hurts)

@@ -192,7 +192,10 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
                 // Alone in its support ball: every term of the sum is exactly 0 and only the nearest
                 // neighbour (nn_dist / nn_id) is still unknown — a 2-nearest search (self + one) gives
                 // the same step as the k-list would, for a fraction of the block and no real selection.
-                if (!overflow && m == 1) Kq = 2;
+                if (!overflow && m == 1) {
+                    Kq = 2;
+                    r2 = 1; // its nearest neighbour is most likely still inside the 27 cells
+                }
                 overflow = false;
                 continue; // general path
             }
