@@ -205,31 +205,76 @@ __global__ __launch_bounds__(kB64Threads, 2) void brick_cs_kernel(SearchArgs<T> 
             bool giveup = false;
             int ra = 0; // ring entries
 
-            // ---- scan the 9 x-rows of the 3x3x3 neighbourhood, kB64SU candidates per step ------------
-            for (int row = 0; row < 9; ++row) {
-                const int dz = row / 3 - 1, dy = row % 3 - 1;
-                const int base = ((hz + dz) * HY + (hy + dy)) * HX + (hx - 1);
-                int pa = sm->hstart[base];
-                const int ea = sm->hstart[base + 3];
-                while (__any(pa < ea)) {
-                    if (__any(ra > kB64Ring - kB64SU)) { // some lane's ring is full (dense cluster): it gives up
-                        if (ra > kB64Ring - kB64SU) {
-                            giveup = true;
-                            ra = 0;
-                            tau_s = (T)-1;
-                        }
-                    }
+            // ---- scan: trimmed per-lane rows (same scheme as brick_kernel<1,0,1>, WTP_LANE_ROWS=2) -----------
+            // A row (dy, dz) lies at least gy, gz from the query (distance to its own cell's faces less the
+            // cell map's rounding margin): only candidates within rem = tau - gy^2 - gz^2 along x can pass the
+            // filter, so the row is dropped when rem < 0 and its end cells when the query is farther than
+            // sqrt(rem) from the own cell's x faces.  The surviving runs are queued as start | end << 16
+            // (LDS point indices) in nine registers; a lane takes its next run by a register shift.
+            uint32_t rq[9] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+            int rn = 0;
+            {
+                const T cxl = g.org[0] + (T)cx * g.c, cyl = g.org[1] + (T)cy * g.c, czl = g.org[2] + (T)cz * g.c;
+                auto gap2 = [&](T d) {
+                    const T t = d - g.margin;
+                    return t > (T)0 ? t * t : (T)0;
+                };
+                const T lx2 = gap2(qp.x - cxl), ux2 = gap2(cxl + g.c - qp.x);
+                const T ly2 = gap2(qp.y - cyl), uy2 = gap2(cyl + g.c - qp.y);
+                const T lz2 = gap2(qp.z - czl), uz2 = gap2(czl + g.c - qp.z);
+                const int base0 = (hz * HY + hy) * HX + (hx - 1);
+                uint32_t st[9], en[9];
 #pragma unroll
-                    for (int u = 0; u < kB64SU; ++u) {
-                        const Pt<T> c = pts[pa + u]; // past the run end: the next cell or the padding, masked below
-                        const T ex = qp.x - c.x, ey = qp.y - c.y, ez = qp.z - c.z;
-                        const T d = fma_t64(ez, ez, fma_t64(ey, ey, ex * ex));
-                        const bool take = (pa + u < ea) && (d <= tau_s);
-                        ring[(take ? ra : kB64Ring) * kB64Threads] = (uint16_t)(pa + u);
-                        ra += take ? 1 : 0;
-                    }
-                    pa += kB64SU;
+                for (int r9 = 0; r9 < 9; ++r9) {
+                    const int dzr = r9 / 3, dyr = r9 % 3;
+                    const T gy2 = dyr == 0 ? ly2 : (dyr == 2 ? uy2 : (T)0);
+                    const T gz2 = dzr == 0 ? lz2 : (dzr == 2 ? uz2 : (T)0);
+                    const T rem = tau_s - gy2 - gz2;
+                    const int rb = base0 + (dzr - 1) * (HY * HX) + (dyr - 1) * HX;
+                    const int i0 = rb + (lx2 <= rem ? 0 : 1), i1 = rb + (ux2 <= rem ? 3 : 2);
+                    st[r9] = (uint32_t)sm->hstart[i0];
+                    en[r9] = rem < (T)0 ? st[r9] : (uint32_t)sm->hstart[i1];
                 }
+#pragma unroll
+                for (int r9 = 0; r9 < 9; ++r9) {
+                    const bool put = en[r9] > st[r9];
+                    const uint32_t pk = st[r9] | (en[r9] << 16);
+#pragma unroll
+                    for (int u9 = 0; u9 < 9; ++u9) rq[u9] = (put && rn == u9) ? pk : rq[u9];
+                    rn += put ? 1 : 0;
+                }
+            }
+            int pa = 0, ea = 0;
+            auto advance = [&]() {
+                if (pa >= ea && rn > 0) {
+                    const uint32_t pk = rq[0];
+#pragma unroll
+                    for (int u9 = 0; u9 < 8; ++u9) rq[u9] = rq[u9 + 1];
+                    --rn;
+                    pa = (int)(pk & 0xFFFFu);
+                    ea = (int)(pk >> 16);
+                }
+            };
+            advance();
+            while (__any(pa < ea)) {
+                if (__any(ra > kB64Ring - kB64SU)) { // some lane's ring is full (dense cluster): it gives up
+                    if (ra > kB64Ring - kB64SU) {
+                        giveup = true;
+                        ra = 0;
+                        tau_s = (T)-1;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kB64SU; ++u) {
+                    const Pt<T> c = pts[pa + u]; // past the run end: the next cell or the padding, masked below
+                    const T ex = qp.x - c.x, ey = qp.y - c.y, ez = qp.z - c.z;
+                    const T d = fma_t64(ez, ez, fma_t64(ey, ey, ex * ex));
+                    const bool take = (pa + u < ea) && (d <= tau_s);
+                    ring[(take ? ra : kB64Ring) * kB64Threads] = (uint16_t)(pa + u);
+                    ra += take ? 1 : 0;
+                }
+                pa += kB64SU;
+                advance();
             }
             const int cnt = ra;
             bool fallback = giveup || cs_fail;
