@@ -31,7 +31,8 @@ __global__ void load_points_kernel(const T* __restrict__ xyz, Pt<T>* __restrict_
 }
 
 template <typename T>
-__global__ void bbox_kernel(const Pt<T>* __restrict__ pts, int64_t n, T* __restrict__ part) {
+__global__ void bbox_kernel(const Pt<T>* __restrict__ pts, int64_t n, T* __restrict__ part, int64_t v_old = 0,
+                            int32_t v_fixed_old = 0) {
     __shared__ T sm[6][kThreads / 64];
     T mn[3] = {Lim<T>::inf(), Lim<T>::inf(), Lim<T>::inf()};
     T mx[3] = {-Lim<T>::inf(), -Lim<T>::inf(), -Lim<T>::inf()};
@@ -39,6 +40,7 @@ __global__ void bbox_kernel(const Pt<T>* __restrict__ pts, int64_t n, T* __restr
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
         Pt<T> p = pts[i];
+        if (i < v_old && w_to_id(p.w) < v_fixed_old) continue; // stale fixed point of the input view
         // non-finite coordinates (x - x != 0) do not shape the box; such points end up in edge cells
         if (!(p.x - p.x == (T)0)) p.x = mn[0] < mx[0] ? mn[0] : (T)0;
         if (!(p.y - p.y == (T)0)) p.y = mn[1] < mx[1] ? mn[1] : (T)0;
@@ -167,7 +169,8 @@ __global__ void grid_setup_kernel(const T* __restrict__ part, int nparts, Grid<T
 
 template <typename T>
 __global__ void cell_rank_kernel(const Pt<T>* __restrict__ pts, int64_t n, const Grid<T>* __restrict__ gp,
-                                 int32_t* __restrict__ cell_cnt, int2* __restrict__ cell_rank) {
+                                 int32_t* __restrict__ cell_cnt, int2* __restrict__ cell_rank, int64_t v_old,
+                                 int32_t v_fixed_old) {
     const Grid<T> g = *gp;
     const int lane = threadIdx.x & 63;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -175,12 +178,15 @@ __global__ void cell_rank_kernel(const Pt<T>* __restrict__ pts, int64_t n, const
     // cell: one atomic per run of equal cells instead of one per point (~8x fewer atomics).
     for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < n; base += stride) {
         const int64_t i = base + threadIdx.x;
-        const bool valid = i < n;
+        bool valid = i < n;
         int cell = -1;
         if (valid) {
             Pt<T> p = pts[i];
-            int cx = cell_coord(g, p.x, 0), cy = cell_coord(g, p.y, 1), cz = cell_coord(g, p.z, 2);
-            cell = (cz * g.n[1] + cy) * g.n[0] + cx;
+            valid = !(i < v_old && w_to_id(p.w) < v_fixed_old); // stale fixed point of the input view: dropped
+            if (valid) {
+                int cx = cell_coord(g, p.x, 0), cy = cell_coord(g, p.y, 1), cz = cell_coord(g, p.z, 2);
+                cell = (cz * g.n[1] + cy) * g.n[0] + cx;
+            }
         }
         const int prev = __shfl_up(cell, 1, 64);
         const bool head = (lane == 0) || (prev != cell);
@@ -295,12 +301,19 @@ __global__ void scan_apply_kernel(const int32_t* __restrict__ cnt, const int32_t
 
 template <typename T>
 __global__ void scatter_kernel(const Pt<T>* __restrict__ pts, int64_t n, const int2* __restrict__ cell_rank,
-                               const int32_t* __restrict__ cell_start, Pt<T>* __restrict__ out) {
+                               const int32_t* __restrict__ cell_start, Pt<T>* __restrict__ out, int64_t v_old,
+                               int32_t v_fixed_old, int32_t v_id_shift) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
+        Pt<T> p = pts[i];
+        if (i < v_old) { // input view: stale fixed points are dropped, the others follow the resized head
+            const int32_t id = w_to_id(p.w);
+            if (id < v_fixed_old) continue;
+            p.w = id_to_w((T)0, id + v_id_shift);
+        }
         int2 cr = cell_rank[i];
-        out[cell_start[cr.x] + cr.y] = pts[i];
+        out[cell_start[cr.x] + cr.y] = p;
     }
 }
 
@@ -625,11 +638,17 @@ int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, in
     const int cap = cell_capacity(ctx, n, k_cap > 0 ? k_cap : 1, cell_scale);
     int rc;
     if ((rc = ensure(ctx, ctx->grid, sizeof(Grid<double>)))) return rc;
-    const int nbb = grid_for(n, kThreads, 1024);
+    // n = points of the structure; the input array may be longer (ctx->hash_view: stale fixed points
+    // still in place, new ones appended)
+    const HashView hv = ctx->hash_view;
+    const int64_t n_in = hv.active ? hv.n_in : n;
+    const int64_t v_old = hv.active ? hv.n_old : 0;
+    const int32_t v_fixed_old = hv.active ? hv.fixed_old : 0, v_shift = hv.active ? hv.id_shift : 0;
+    const int nbb = grid_for(n_in, kThreads, 1024);
     if ((rc = ensure(ctx, ctx->bbox_part, sizeof(double) * 6 * 1024))) return rc;
     if ((rc = ensure(ctx, ctx->cell_cnt, sizeof(int32_t) * (size_t)(cap + 1)))) return rc;
     if ((rc = ensure(ctx, ctx->cell_start, sizeof(int32_t) * (size_t)(cap + 2)))) return rc;
-    if ((rc = ensure(ctx, ctx->cell_of, sizeof(int2) * (size_t)n))) return rc;
+    if ((rc = ensure(ctx, ctx->cell_of, sizeof(int2) * (size_t)n_in))) return rc;
     const int nscan = (cap + kScanTile - 1) / kScanTile;
     if ((rc = ensure(ctx, ctx->scan_tmp, sizeof(int32_t) * (size_t)(nscan + 1)))) return rc;
 
@@ -647,16 +666,17 @@ int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, in
     if (rho_k < 1.0) rho_k = 1.0;
 
     WTP_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)(cap + 1), st));
-    hipLaunchKernelGGL(bbox_kernel<T>, dim3(nbb), dim3(kThreads), 0, st, in, n, part);
+    hipLaunchKernelGGL(bbox_kernel<T>, dim3(nbb), dim3(kThreads), 0, st, in, n_in, part, v_old, v_fixed_old);
     hipLaunchKernelGGL(grid_setup_kernel<T>, dim3(1), dim3(64), 0, st, part, nbb, g, n, dim, rho_k, radius, min_cell, cap,
                        cell_scale, ctx->box_active ? (const double*)ctx->box_dev.p : (const double*)nullptr);
     ctx->ncells_dev = &g->ncells;
-    const int nb = grid_for(n, kThreads, 16384);
-    hipLaunchKernelGGL(cell_rank_kernel<T>, dim3(nb), dim3(kThreads), 0, st, in, n, g, cnt, cr);
+    const int nb = grid_for(n_in, kThreads, 16384);
+    hipLaunchKernelGGL(cell_rank_kernel<T>, dim3(nb), dim3(kThreads), 0, st, in, n_in, g, cnt, cr, v_old, v_fixed_old);
     hipLaunchKernelGGL(scan_reduce_kernel<T>, dim3(nscan), dim3(kThreads), 0, st, cnt, g, bs);
     hipLaunchKernelGGL(scan_top_kernel<T>, dim3(1), dim3(kThreads), 0, st, bs, g);
     hipLaunchKernelGGL(scan_apply_kernel<T>, dim3(nscan), dim3(kThreads), 0, st, cnt, bs, g, start);
-    hipLaunchKernelGGL(scatter_kernel<T>, dim3(nb), dim3(kThreads), 0, st, in, n, cr, start, out);
+    hipLaunchKernelGGL(scatter_kernel<T>, dim3(nb), dim3(kThreads), 0, st, in, n_in, cr, start, out, v_old, v_fixed_old,
+                       v_shift);
     hipLaunchKernelGGL(canon_kernel<T>, dim3(grid_for(cap, kThreads, 8192)), dim3(kThreads), 0, st, out, start, g);
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;
@@ -1035,6 +1055,22 @@ __global__ void refix_kernel(const Pt<T>* __restrict__ in, int64_t n_old, int32_
 }
 
 template <typename T>
+__global__ void append_fixed_kernel(const Pt<T>* __restrict__ src, int64_t n, Pt<T>* __restrict__ dst) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        Pt<T> p = src[j];
+        p.w = id_to_w((T)0, (int32_t)j);
+        dst[j] = p;
+    }
+}
+
+template <typename T> int launch_append_fixed(wtp_ctx* ctx, const Pt<T>* d_src, int64_t n, Pt<T>* d_dst) {
+    hipLaunchKernelGGL(append_fixed_kernel<T>, dim3(grid_for(n, kThreads, 4096)), dim3(kThreads), 0, ctx->stream, d_src, n,
+                       d_dst);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
+template <typename T>
 int launch_refix(wtp_ctx* ctx, const Pt<T>* in, int64_t n_old, int64_t n_fixed_old, int64_t n_fixed_new,
                  const Pt<T>* d_fixed_new, Pt<T>* out, int32_t* d_counter) {
     WTP_HIP(ctx, hipMemsetAsync(d_counter, 0, sizeof(int32_t), ctx->stream));
@@ -1052,6 +1088,7 @@ int launch_refix(wtp_ctx* ctx, const Pt<T>* in, int64_t n_old, int64_t n_fixed_o
     template int launch_axis_hist<T>(wtp_ctx*, const Pt<T>*, int64_t, int, const double*, unsigned int*); \
     template int launch_layers<T>(wtp_ctx*, const Pt<T>*, int64_t, int64_t, int, double, double, double, double, \
                                   Pt<T>*, Pt<T>*, int64_t, int2*, int32_t*, bool, double);              \
+    template int launch_append_fixed<T>(wtp_ctx*, const Pt<T>*, int64_t, Pt<T>*);                       \
     template int launch_refix<T>(wtp_ctx*, const Pt<T>*, int64_t, int64_t, int64_t, const Pt<T>*, Pt<T>*, int32_t*); \
     template int load_points<T>(wtp_ctx*, const T*, Pt<T>*, int64_t, int);                              \
     template int build_hash<T>(wtp_ctx*, const Pt<T>*, Pt<T>*, int64_t, int, int, double, double, double, double); \

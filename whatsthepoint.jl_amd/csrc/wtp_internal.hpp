@@ -129,6 +129,17 @@ struct DevBuf {
     size_t cap = 0;
 };
 
+// Input view of a hash build whose input array still holds stale fixed points and has the new
+// ones appended: entry i is dropped when i < n_old and its id < fixed_old; kept entries below
+// n_old get id + id_shift (fixed head resized), entries from n_old on keep their id.
+struct HashView {
+    bool active = false;
+    int64_t n_in = 0;    // entries in the input array
+    int64_t n_old = 0;   // entries of the previous snapshot (stale fixed points among them)
+    int32_t fixed_old = 0;
+    int32_t id_shift = 0;
+};
+
 struct RelaxState {
     bool active = false;
     int64_t n = 0, n_fixed = 0;
@@ -150,6 +161,8 @@ struct RelaxState {
     double spacing_typ = 0;  // mean spacing over the snapshot (floor of the compact-support cell edge)
     bool cs_sweep = false;   // compact-support sweep in use (ClippedSpacingForce)
     double sp_p0 = 0, sp_p1 = 0, sp_p2 = 0; // LOGLIKE / BOUNDARY_LAYER parameters
+    HashView pending;        // wtp_relax_set_fixed_dev left its work to the next rebuild (see there)
+    int64_t shard_extra = 0; // extra capacity of the point buffers once the fixed head gets replaced
     int cover_axis = -1;     // sharded session: snapshot complete for cover_lo <= coord[axis] <= cover_hi
     double cover_lo = 0, cover_hi = 0;
 };
@@ -178,6 +191,7 @@ struct wtp_ctx {
     wtp::DevBuf raw_in;        // AoS staging of host input
     wtp::DevBuf cell_of, rank_of, cell_cnt, cell_start, scan_tmp;
     wtp::DevBuf grid, bbox_part, occ;
+    wtp::HashView hash_view;   // consumed by the next build_hash call (set and cleared by the caller)
     wtp::DevBuf box_dev;       // robust box {lo xyz, hi xyz} (doubles) + histogram scratch behind it
     bool box_active = false;   // grid_setup clips the bounding box to box_dev (outliers piled into edge cells)
     const void* ncells_dev = nullptr; // device address of Grid::ncells of the last build_hash
@@ -309,6 +323,7 @@ template <typename T>
 int launch_layers(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int64_t n_fixed, int axis, double lo_in, double hi_in,
                   double lo_out, double hi_out, Pt<T>* d_lo, Pt<T>* d_hi, int64_t cap, int2* d_blk, int32_t* d_totals,
                   bool slot_ordered, double reach);
+template <typename T> int launch_append_fixed(wtp_ctx* ctx, const Pt<T>* d_src, int64_t n, Pt<T>* d_dst);
 template <typename T>
 int launch_refix(wtp_ctx* ctx, const Pt<T>* in, int64_t n_old, int64_t n_fixed_old, int64_t n_fixed_new,
                  const Pt<T>* d_fixed_new, Pt<T>* out, int32_t* d_counter);
