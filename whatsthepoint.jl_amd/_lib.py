@@ -77,6 +77,7 @@ SIGNATURES = {
     "wtp_relax_set_coverage": (_i, [_vp, _i, _d, _d]),
     "wtp_timers_get": (_i, [_vp, C.POINTER(_d)]),
     "wtp_timers_reset": (_i, [_vp]),
+    "wtp_debug_diag": (_i, [_vp, C.POINTER(C.c_ulonglong)]),
     "wtp_gen_uniform_dev": (_i, [_vp, C.c_uint64, _i64, _i64, _i, _i, _vp]),
 }
 
