@@ -435,7 +435,7 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
             int lr_n = 0;
             for (;;) {
                 bool pressure = false;
-                if (CS && WTP_LANE_ROWS == 2) {
+                if (WTP_LANE_ROWS == 2) {
                     // Per-lane rows WITH trimming: a row (dy, dz) of the neighbourhood lies at least
                     // gy, gz away from the query along y and z (distance to its own cell's faces, less the
                     // cell map's rounding margin), so only candidates within rem = tau - gy^2 - gz^2 along
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
                             const int dzr = r9 / 3, dyr = r9 % 3;
                             const float gy2 = dyr == 0 ? ly2 : (dyr == 2 ? uy2 : 0.f);
                             const float gz2 = dzr == 0 ? lz2 : (dzr == 2 ? uz2 : 0.f);
-                            const float rem = tau_s - gy2 - gz2;
+                            const float rem = (CS ? tau_s : tau) - gy2 - gz2; // tau only shrinks afterwards: still conservative
                             const int rb = base0 + (dzr - 1) * (HY * HX) + (dyr - 1) * HX;
                             const int i0 = rb + (lx2 <= rem ? 0 : 1), i1 = rb + (ux2 <= rem ? 3 : 2);
                             st[r9] = (uint32_t)sm->hstart[i0];
@@ -501,10 +501,16 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
                         lds_read_group(c, lds_base + pa);
 #pragma unroll
                         for (int u = 0; u < SU; ++u) {
-                            const float ex = qp.x - c[u].x, ey = qp.y - c[u].y, ez = qp.z - c[u].z;
-                            const float d = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
-                            const float tl = (pa + 16u * u < ea) ? tau_s : -1.f;
-                            const bool take = d <= tl;
+                            float d;
+                            if (CS) {
+                                const float ex = qp.x - c[u].x, ey = qp.y - c[u].y, ez = qp.z - c[u].z;
+                                d = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
+                            } else {
+                                d = dist2<float>(qp.x, qp.y, qp.z, c[u].x, c[u].y, c[u].z);
+                            }
+                            const float tl = (pa + 16u * u < ea) ? (CS ? tau_s : tau) : -1.f;
+                            bool take = d <= tl;
+                            if (MODE == 0) take = take && (w_to_id(c[u].w) != skip_id);
                             *reinterpret_cast<uint16_t*>(smem_raw + (take ? ra : dump_b)) = (uint16_t)(pa + 16u * u);
                             ra += take ? (kBrickThreads * 2u) : 0u;
                         }
