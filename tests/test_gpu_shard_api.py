@@ -140,3 +140,33 @@ def test_set_fixed_rejects_per_point_spacing(wtp, ctx):
     with ctx.relax(x, 0, sp, FORCE, 21, 1e-5, 1e-3) as t:
         with pytest.raises(wtp.WtpError):
             t.set_fixed_dev(0, 0)
+
+
+def test_reading_the_state_between_set_fixed_and_step(wtp, ctx):
+    """wtp_relax_set_fixed_dev only appends the new head and leaves the clean-up to the next hash
+    build; any entry point that reads the state in between has to materialise it first."""
+    torch = _torch()
+    n_own, k = 30000, 21
+    s = n_own ** (-1.0 / 3.0)
+    own = wtp.synth.uniform(n_own, 3, np.float32, 5)
+    g1 = wtp.synth.uniform(4000, 3, np.float32, 6)
+    g2 = wtp.synth.uniform(6000, 3, np.float32, 8)
+    with ctx.relax(own, 0, s, FORCE, k, s / 2000, s / 20) as sess:
+        d1 = _dev(_rows4(g1))
+        sess.set_fixed_dev(d1.data_ptr(), len(g1))           # first call: rewrites once (buffers had no room)
+        sess.step(True)
+        p1 = sess.positions()
+        d2 = _dev(_rows4(g2))
+        sess.set_fixed_dev(d2.data_ptr(), len(g2))           # pending view
+        assert np.array_equal(sess.positions(), p1)          # read-back in between: same owned positions
+        lo = torch.zeros((n_own, 4), dtype=torch.float32, device="cuda")
+        hi = torch.zeros((n_own, 4), dtype=torch.float32, device="cuda")
+        cnt = sess.layers_dev(2, 0.3, 0.6, -1.0, 2.0, lo.data_ptr(), hi.data_ptr(), n_own)
+        assert cnt[0] == int((p1[:, 2] < np.float32(0.3)).sum()) and cnt[1] == int((p1[:, 2] >= np.float32(0.6)).sum())
+        d3 = _dev(_rows4(g1))
+        sess.set_fixed_dev(d3.data_ptr(), len(g1))           # and a second replacement before any step
+        st = sess.step(True)
+        p2 = sess.positions()
+    with ctx.relax(np.concatenate([g1, p1]), len(g1), s, FORCE, k, s / 2000, s / 20) as ref:
+        st_ref = ref.step(True)
+        assert np.array_equal(p2, ref.positions()) and st["max_force"] == st_ref["max_force"]
