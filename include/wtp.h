@@ -230,6 +230,12 @@ int wtp_set_stream(wtp_ctx* ctx, void* hip_stream, int external);
 int wtp_relax_layers_dev(wtp_ctx* ctx, int axis, double lo_in, double hi_in, double lo_out, double hi_out,
                          void* d_lo4, void* d_hi4, int64_t cap, int64_t counts[4]);
 
+/* wtp_relax_step followed by wtp_relax_layers_dev on the positions it produced, with one read-back
+ * and one synchronisation for both: the layers of iteration i+1 come home with the statistics of
+ * iteration i.  */
+int wtp_relax_step_layers(wtp_ctx* ctx, int rebuild, wtp_step_stats* stats, int axis, double lo_in, double hi_in,
+                          double lo_out, double hi_out, void* d_lo4, void* d_hi4, int64_t cap, int64_t counts[4]);
+
 /* Coverage of a sharded session: the caller guarantees that the snapshot holds every point of
  * the global cloud with lo <= coord[axis] <= hi (its slab plus the ghost layers; an end may be
  * +-inf).  A sweep then counts in stats.n_uncovered the movable points whose answer needs more:

@@ -51,6 +51,10 @@ class ResidentOracleEngine(OracleEngine):
         self.x, st = self.sweep(torch.cat([self.g, self.x]).contiguous(), len(self.g))
         return st
 
+    def step_and_layers(self, axis, lo_in, hi_in, lo_out, hi_out):
+        st = self.step()
+        return st, self.layers(axis, lo_in, hi_in, lo_out, hi_out)
+
     def positions(self):
         return self.x
 

@@ -34,16 +34,22 @@ eng.open(x)
 shift = torch.tensor([0, 0, L, 0], dtype=torch.float32, device="cuda")
 
 
+nxt = [None]
+
+
 def iteration(sync_each=False, T=None):
     t0 = time.perf_counter()
-    lo_rows, hi_rows, stray = eng.layers(2, w_eff, L - w_eff, -margin, L + margin)
+    if nxt[0] is None:
+        lo_rows, hi_rows, stray = eng.layers(2, w_eff, L - w_eff, -margin, L + margin)
+    else:
+        lo_rows, hi_rows, stray = nxt[0]
     if T is not None:
         torch.cuda.synchronize(); t1 = time.perf_counter(); T[0] += t1 - t0
     g = torch.cat([hi_rows.view(torch.float32) - shift, lo_rows.view(torch.float32) + shift]).view(torch.int32)
     eng.set_ghosts(g)
     if T is not None:
         torch.cuda.synchronize(); t2 = time.perf_counter(); T[1] += t2 - t1
-    st = eng.step()
+    st, nxt[0] = eng.step_and_layers(2, w_eff, L - w_eff, -margin, L + margin)
     if T is not None:
         t3 = time.perf_counter(); T[2] += t3 - t2
     return st, g.shape[0]

@@ -1229,15 +1229,12 @@ WTP_API int wtp_set_stream(wtp_ctx* ctx, void* hip_stream, int external) {
     return WTP_OK;
 }
 
-WTP_API int wtp_relax_layers_dev(wtp_ctx* ctx, int axis, double lo_in, double hi_in, double lo_out, double hi_out,
-                                 void* d_lo4, void* d_hi4, int64_t cap, int64_t counts[4]) {
-    if (!ctx) return WTP_ERR_ARG;
+// launches the two layer kernels on the current P; *d_tot_out = device address of the four counts
+static int enqueue_layers(wtp_ctx* ctx, int axis, double lo_in, double hi_in, double lo_out, double hi_out, void* d_lo4,
+                          void* d_hi4, int64_t cap, int32_t** d_tot_out) {
     RelaxState& r = ctx->relax;
-    if (!r.active) return fail(ctx, WTP_ERR_STATE, "wtp_relax_layers_dev before wtp_relax_init");
     if (axis < 0 || axis >= r.dim) return fail(ctx, WTP_ERR_ARG, "axis must be in [0, dim)");
     if (cap < 0 || (cap > 0 && (!d_lo4 || !d_hi4))) return fail(ctx, WTP_ERR_ARG, "layer buffers are NULL");
-    if (!counts) return fail(ctx, WTP_ERR_ARG, "counts is NULL");
-    WTP_HIP(ctx, hipSetDevice(ctx->device));
     if (int rcf = flush_pending(ctx)) return rcf;
     int rc;
     const int nblk = layer_blocks(r.n);
@@ -1255,11 +1252,49 @@ WTP_API int wtp_relax_layers_dev(wtp_ctx* ctx, int axis, double lo_in, double hi
     else
         rc = launch_layers<double>(ctx, (const double4*)ctx->pts[r.bufP].p, r.n, r.n_fixed, axis, lo_in, hi_in, lo_out,
                                    hi_out, (double4*)d_lo4, (double4*)d_hi4, cap, d_blk, d_tot, slot_ordered, reach);
-    if (rc) return rc;
+    *d_tot_out = d_tot;
+    return rc;
+}
+
+WTP_API int wtp_relax_layers_dev(wtp_ctx* ctx, int axis, double lo_in, double hi_in, double lo_out, double hi_out,
+                                 void* d_lo4, void* d_hi4, int64_t cap, int64_t counts[4]) {
+    if (!ctx) return WTP_ERR_ARG;
+    RelaxState& r = ctx->relax;
+    if (!r.active) return fail(ctx, WTP_ERR_STATE, "wtp_relax_layers_dev before wtp_relax_init");
+    if (!counts) return fail(ctx, WTP_ERR_ARG, "counts is NULL");
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    int32_t* d_tot = nullptr;
+    if ((rc = enqueue_layers(ctx, axis, lo_in, hi_in, lo_out, hi_out, d_lo4, d_hi4, cap, &d_tot))) return rc;
     if ((rc = ensure_pinned(ctx, 64))) return rc;
     WTP_HIP(ctx, hipMemcpyAsync(ctx->host_pinned, d_tot, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     if ((rc = sync(ctx))) return rc;
     for (int j = 0; j < 4; ++j) counts[j] = ((const int32_t*)ctx->host_pinned)[j];
+    return WTP_OK;
+}
+
+// One sweep and, from the positions it produced, the boundary layers of the NEXT iteration, with a
+// single read-back and a single synchronisation for both (a sharded iteration otherwise pays two).
+WTP_API int wtp_relax_step_layers(wtp_ctx* ctx, int rebuild, wtp_step_stats* stats, int axis, double lo_in, double hi_in,
+                                  double lo_out, double hi_out, void* d_lo4, void* d_hi4, int64_t cap,
+                                  int64_t counts[4]) {
+    if (!ctx) return WTP_ERR_ARG;
+    if (!ctx->relax.active) return fail(ctx, WTP_ERR_STATE, "wtp_relax_step_layers before wtp_relax_init");
+    if (!stats || !counts) return fail(ctx, WTP_ERR_ARG, "stats/counts is NULL");
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, ctx->stats, sizeof(wtp_step_stats)))) return rc;
+    if ((rc = relax_step_any(ctx, rebuild, (wtp_step_stats*)ctx->stats.p))) return rc;
+    int32_t* d_tot = nullptr;
+    if ((rc = enqueue_layers(ctx, axis, lo_in, hi_in, lo_out, hi_out, d_lo4, d_hi4, cap, &d_tot))) return rc;
+    const size_t off = (sizeof(wtp_step_stats) + 63) / 64 * 64;
+    if ((rc = ensure_pinned(ctx, off + 64))) return rc;
+    WTP_HIP(ctx, hipMemcpyAsync(ctx->host_pinned, ctx->stats.p, sizeof(wtp_step_stats), hipMemcpyDeviceToHost, ctx->stream));
+    WTP_HIP(ctx, hipMemcpyAsync((char*)ctx->host_pinned + off, d_tot, 4 * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    if ((rc = sync(ctx))) return rc;
+    memcpy(stats, ctx->host_pinned, sizeof(wtp_step_stats));
+    for (int j = 0; j < 4; ++j) counts[j] = ((const int32_t*)((const char*)ctx->host_pinned + off))[j];
     return WTP_OK;
 }
 

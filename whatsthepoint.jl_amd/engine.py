@@ -293,6 +293,17 @@ class RelaxSession:
         L.check(self.ctx._h, rc)
         return tuple(int(c) for c in cnt)
 
+    def step_layers(self, rebuild, axis, lo_in, hi_in, lo_out, hi_out, d_lo_ptr, d_hi_ptr, cap):
+        """One sweep + the boundary layers of the positions it produced, one synchronisation for both:
+        returns (stats, (n_lo, n_hi, n_stray_lo, n_stray_hi))."""
+        st = L.StepStats()
+        cnt = (C.c_int64 * 4)()
+        rc = self._lib.wtp_relax_step_layers(self.ctx._h, int(bool(rebuild)), C.byref(st), int(axis), float(lo_in),
+                                             float(hi_in), float(lo_out), float(hi_out), C.c_void_p(d_lo_ptr),
+                                             C.c_void_p(d_hi_ptr), int(cap), cnt)
+        L.check(self.ctx._h, rc)
+        return _stats_dict(st), tuple(int(c) for c in cnt)
+
     def set_fixed_dev(self, d_fixed4_ptr: int, n_fixed_new: int):
         """Replace the fixed head of the snapshot by n_fixed_new packed 4-vectors in device memory."""
         rc = self._lib.wtp_relax_set_fixed_dev(self.ctx._h, C.c_void_p(d_fixed4_ptr) if n_fixed_new else None,

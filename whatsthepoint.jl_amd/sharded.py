@@ -87,6 +87,18 @@ class GpuEngine:
     def step(self):
         return self.sess.step(True)
 
+    def step_and_layers(self, axis, lo_in, hi_in, lo_out, hi_out):
+        """One sweep and, from the positions it produced, the next iteration's boundary layers — one
+        synchronisation for both.  Returns (stats, (lo rows, hi rows, strays)) or (stats, None) when a
+        layer outgrew its buffer (the caller then asks layers() again, which grows it)."""
+        if self._cap == 0:
+            self._grow(max(4096, self.n_own // 8))
+        st, (n_lo, n_hi, s_lo, s_hi) = self.sess.step_layers(True, axis, lo_in, hi_in, lo_out, hi_out,
+                                                              self._lo.data_ptr(), self._hi.data_ptr(), self._cap)
+        if max(n_lo, n_hi) > self._cap:
+            return st, None
+        return st, (self._lo[:n_lo], self._hi[:n_hi], s_lo + s_hi)
+
     def positions(self) -> torch.Tensor:
         out = torch.empty((self.n_own, 3), dtype=torch.float32, device=self.dev)
         if self.n_own:
@@ -151,6 +163,8 @@ class ShardedRelax:
         self._wall_local = None
         self._wall_w = None
         self._wall_set = False
+        self._next_layers = None      # boundary layers extracted together with the previous sweep
+        self._next_layers_key = None  # ... for these planes
         self.last_local_points = int(owned_xyz.shape[0])
         self.history = []
 
@@ -280,8 +294,14 @@ class ShardedRelax:
         n_ghost = 0
         if self.world > 1:
             w_eff = self.w + self.margin
-            # 1. boundary layers straight from the library's state; strays decide on migration
-            lo_rows, hi_rows, n_stray = eng.layers(2, lo + w_eff, hi - w_eff, lo - self.margin, hi + self.margin)
+            # 1. boundary layers straight from the library's state (usually extracted together with the
+            #    previous sweep); strays decide on migration
+            planes = (2, lo + w_eff, hi - w_eff, lo - self.margin, hi + self.margin)
+            if self._next_layers is not None and self._next_layers_key == planes:
+                lo_rows, hi_rows, n_stray = self._next_layers
+            else:
+                lo_rows, hi_rows, n_stray = eng.layers(*planes)
+            self._next_layers = None
             migrate = n_stray > 0
             split_lo = split_hi = 0
             emigrants = []
@@ -330,7 +350,11 @@ class ShardedRelax:
             n_ghost = int(self.wall.shape[0])
         n_own = int(self.gid.shape[0])
         self.last_local_points = n_own + n_ghost
-        st = eng.step()
+        if self.world > 1 and hasattr(eng, "step_and_layers"):
+            st, self._next_layers = eng.step_and_layers(*planes)
+            self._next_layers_key = planes
+        else:
+            st = eng.step()
         out = self._reduce(st, n_ghost, n_own)
         if out["n_uncovered"] > 0:
             # some rank's sweep needed points beyond its ghost layer (a k-th neighbour past the cover):
@@ -338,6 +362,7 @@ class ShardedRelax:
             if attempt >= 4 or not hasattr(eng, "revert"):
                 raise RuntimeError(f"{out['n_uncovered']} queries reach past the ghost layer (w={self.w:g})")
             eng.revert()
+            self._next_layers = None
             self.history.pop()
             self.w *= 1.5
             self.widened += 1
