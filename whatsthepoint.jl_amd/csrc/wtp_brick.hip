@@ -741,7 +741,7 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
                     a.forces[gslot] = f;
                     a.nn_dist[gslot] = nd;
                     a.nn_id[gslot] = has ? nid : -1;
-                    acc_point(acc, (double)f, (double)nd, (double)s, qid, has ? nid : -1);
+                    acc_point<float>(acc, f, nd, s, qid, has ? nid : -1);
                 }
             }
             if (fallback) {

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(kB64Threads, 2) void brick_cs_kernel(SearchArgs<T> 
             a.forces[gslot] = f;
             a.nn_dist[gslot] = nd;
             a.nn_id[gslot] = nid;
-            acc_point(acc, (double)f, (double)nd, (double)s, qid, nid);
+            acc_point<T>(acc, f, nd, s, qid, nid);
         }
     }
     __syncthreads();

@@ -193,10 +193,13 @@ __device__ inline Acc acc_empty() {
     return a;
 }
 
-__device__ inline void acc_point(Acc& acc, double force, double nn_dist, double s, int64_t id,
-                                 int64_t nn) {
+// u = nn_dist / spacing is formed in the cloud's float type, like `_dnn_cv` does
+// (src/repel.jl:376-381: U = typeof(one(T)/one(eltype(spacings)))), then accumulated in double.
+template <typename T>
+__device__ inline void acc_point(Acc& acc, T force_t, T nn_dist_t, T s, int64_t id, int64_t nn) {
+    const double force = (double)force_t, nn_dist = (double)nn_dist_t;
     acc.max_force = force > acc.max_force ? force : acc.max_force;
-    double u = nn_dist / s; // _dnn_cv term, src/repel.jl:380 (callers pass the T-typed quotient when they have it)
+    const double u = (double)(nn_dist_t / s);
     acc.sum_u += u;
     acc.sum_u2 += u * u;
     acc.n_move += 1;

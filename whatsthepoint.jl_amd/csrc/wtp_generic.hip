@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kThreads) void generic_kernel(SearchArgs<T> a, cons
             a.forces[slot] = f;
             a.nn_dist[slot] = nd;
             a.nn_id[slot] = nid;
-            acc_point(acc, (double)f, (double)nd, (double)s, id, nid);
+            acc_point<T>(acc, f, nd, s, id, nid);
             const T need = m == K ? bd[K - 1] : Lim<T>::inf(); // fewer than k local points: nothing is certain
             if (reaches_past_cover<T>(a, q.x, q.y, q.z, need)) atomicAdd(a.uncovered, 1);
         }

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
                 a.forces[slot] = f;
                 a.nn_dist[slot] = nd;
                 a.nn_id[slot] = nid;
-                acc_point(acc, (double)f, (double)nd, (double)s, id, nid);
+                acc_point<T>(acc, f, nd, s, id, nid);
                 // sharded sessions: what the answer rests on — the k-th neighbour, or the support ball
                 const T last = sm->od2[Kq - 1];
                 const T need = cs_done ? cs_lim : (Kq < K ? (last > cs_lim ? last : cs_lim) : last);
