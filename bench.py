@@ -26,6 +26,32 @@ B_ALG_ITER = 91.0    # hash 50 + sweep 41
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
 
 
+def reference_baseline(points: int, iters: int):
+    """The reference's own OhMyThreads path (julia/bench_reference.jl), iff a Julia with WhatsThePoint
+    already installed resolves on this box.  Never installs anything; any failure -> None."""
+    import shutil
+    import subprocess
+
+    julia = shutil.which("julia")
+    if not julia:
+        return None
+    try:
+        chk = subprocess.run([julia, "-e", "using WhatsThePoint"], capture_output=True, text=True, timeout=120)
+        if chk.returncode != 0:
+            return None
+        res = subprocess.run([julia, "--threads=auto", os.path.join(ROOT, "julia", "bench_reference.jl"), str(points),
+                              str(iters)], capture_output=True, text=True, timeout=300)
+        for line in res.stdout.splitlines():
+            if line.startswith("WTP_REFERENCE"):
+                _, val, thr, sec = line.split()
+                return dict(value=float(val), unit="Mpoints/s", cores=int(thr), kind="reference",
+                            sample=f"{iters} repel iterations on {points} uniform fp32 points "
+                                   f"(WhatsThePoint._relax!, OhMyThreads, {float(sec):.1f} s)")
+    except Exception:
+        return None
+    return None
+
+
 def cpu_baseline(points: int, iters: int):
     """The oracle's kd-tree + OpenMP restatement of the same sweep ("port"), timed on this host."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -352,7 +378,9 @@ def main():
                 sess.close()
             out["other_paths"] = other_paths(ctx, torch, np, wtp_amd, args.extra_legs)
         if not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_points, args.cpu_iters)
+            # the reference itself when it is installed on the box (it is not in the build image), else the port
+            out["cpu_baseline"] = reference_baseline(args.cpu_points // 4, args.cpu_iters) or \
+                cpu_baseline(args.cpu_points, args.cpu_iters)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
