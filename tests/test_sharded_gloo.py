@@ -170,7 +170,7 @@ def test_sharded_with_a_global_wall_and_stop_rules(O, wtp, world, resident):
 
 # ---- the same logic with the PRODUCT engine: 2 ranks sharing the one GPU of the test box, payloads
 # staged through host memory because gloo carries CPU tensors (RCCL needs one GPU per rank) ----------
-def _gpu_worker(rank, world, port, n_total, iters, q, ghost_w_over_s=None, n_wall=0):
+def _gpu_worker(rank, world, port, n_total, iters, q, ghost_w_over_s=None, n_wall=0, margin=None):
     for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -193,11 +193,11 @@ def _gpu_worker(rank, world, port, n_total, iters, q, ghost_w_over_s=None, n_wal
     eng = sharded.GpuEngine(ctx, s, dict(kind=2, beta=0.2, u0=1.0, gamma=3.0), k, s / 2000, s / 20)
     w = sharded.ghost_width(n_total, k) if ghost_w_over_s is None else ghost_w_over_s * s
     wall = torch.from_numpy(_wall(wtp_amd, n_wall)).cuda() if n_wall else None
-    drv = sharded.ShardedRelax(eng, dist, xyz, gid, cuts, w, comm_device="cpu", wall_xyz=wall)
+    drv = sharded.ShardedRelax(eng, dist, xyz, gid, cuts, w, comm_device="cpu", wall_xyz=wall, margin=margin)
     conv = drv.relax(max_iters=iters, tol=0.0) if n_wall else [drv.step()["max_force"] for _ in range(iters)]
     allp = drv.gather_global(n_total)
     if rank == 0:
-        q.put((conv, allp.numpy(), drv.widened, drv.w / s))
+        q.put((conv, allp.numpy(), drv.widened, drv.w / s, drv.migrations))
     dist.barrier()
     eng.close()
     ctx.close()
@@ -205,20 +205,21 @@ def _gpu_worker(rank, world, port, n_total, iters, q, ghost_w_over_s=None, n_wal
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ghost_w_over_s,n_wall", [(None, 0), (0.6, 0), (None, 4000)])
-def test_sharded_gpu_engine_two_ranks_one_gpu(O, wtp, ghost_w_over_s, n_wall):
+@pytest.mark.parametrize("ghost_w_over_s,n_wall,margin", [(None, 0, None), (0.6, 0, None), (None, 4000, None),
+                                                         (None, 0, 0.0)])
+def test_sharded_gpu_engine_two_ranks_one_gpu(O, wtp, ghost_w_over_s, n_wall, margin):
     # ghost_w_over_s = 0.6: a ghost layer thinner than the force law's support — the sweep must
     # notice (n_uncovered), and the driver must undo, widen and repeat until the answer is global
     n_total, iters, world = 120000, 3, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, n_total, iters, q, ghost_w_over_s, n_wall))
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, n_total, iters, q, ghost_w_over_s, n_wall, margin))
              for r in range(world)]
     for p in procs:
         p.start()
     try:
-        conv, allp, widened, w_over_s = q.get(timeout=240)
+        conv, allp, widened, w_over_s, migrations = q.get(timeout=240)
         for p in procs:
             p.join(300)
             assert p.exitcode == 0
@@ -227,6 +228,8 @@ def test_sharded_gpu_engine_two_ranks_one_gpu(O, wtp, ghost_w_over_s, n_wall):
             if p.is_alive():
                 p.terminate()
     assert (widened == 0) if ghost_w_over_s is None else (widened >= 2 and w_over_s > 1.0)
+    if margin == 0.0:   # every crossing is handed over at once: the engine's session restarts on the new owned set
+        assert migrations >= 1
     x = wtp.synth.uniform(n_total, 3, np.float32, 7)
     s = float(n_total) ** (-1.0 / 3.0)
     snap = np.concatenate([_wall(wtp, n_wall), x]) if n_wall else x
