@@ -205,12 +205,12 @@ def _gpu_worker(rank, world, port, n_total, iters, q, ghost_w_over_s=None, n_wal
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ghost_w_over_s,n_wall,margin", [(None, 0, None), (0.6, 0, None), (None, 4000, None),
-                                                         (None, 0, 0.0)])
-def test_sharded_gpu_engine_two_ranks_one_gpu(O, wtp, ghost_w_over_s, n_wall, margin):
+@pytest.mark.parametrize("world,ghost_w_over_s,n_wall,margin", [(2, None, 0, None), (2, 0.6, 0, None), (2, None, 4000, None),
+                                                               (2, None, 0, 0.0), (3, None, 0, None)])
+def test_sharded_gpu_engine_two_ranks_one_gpu(O, wtp, world, ghost_w_over_s, n_wall, margin):
     # ghost_w_over_s = 0.6: a ghost layer thinner than the force law's support — the sweep must
     # notice (n_uncovered), and the driver must undo, widen and repeat until the answer is global
-    n_total, iters, world = 120000, 3, 2
+    n_total, iters = 120000, 3   # world = 3: an interior rank with two neighbours
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
