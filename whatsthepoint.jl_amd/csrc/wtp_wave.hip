@@ -110,7 +110,9 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
         for (int r2 = all ? 1 : 2;;) {
             const int r = cs_try ? cs_r : r2;
             m = 0;
-            const T g2 = cs_try ? cs_lim : safe_radius2(g, q.x, q.y, q.z, cx, cy, cz, r);
+            // the support-ball attempt gathers everything the block certifies (>= the ball), so that a query
+            // alone in its ball finds its nearest neighbour in the same list
+            const T g2 = safe_radius2(g, q.x, q.y, q.z, cx, cy, cz, r);
             const int z0 = cz - r < 0 ? 0 : cz - r, z1 = cz + r > g.n[2] - 1 ? g.n[2] - 1 : cz + r;
             const int y0 = cy - r < 0 ? 0 : cy - r, y1 = cy + r > g.n[1] - 1 ? g.n[1] - 1 : cy + r;
             const int x0 = cx - r < 0 ? 0 : cx - r, x1 = cx + r > g.n[0] - 1 ? g.n[0] - 1 : cx + r;
@@ -184,17 +186,26 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
             }
             if (cs_try) {
                 cs_try = false;
-                if (!overflow && m >= 2 && m <= K) {
-                    Kq = m;
-                    cs_done = true;
+                int m_lim = 0; // population of the support ball (self included)
+                if (!overflow) {
+                    for (int i0 = 0; i0 < m; i0 += 64) {
+                        const int i = i0 + lane;
+                        m_lim += __popcll(__ballot(i < m && sm->d2[i] <= cs_lim));
+                    }
+                }
+                if (!overflow && m_lim >= 2 && m_lim <= K) {
+                    Kq = m_lim;
+                    cs_done = true; // the answer is everything within the ball: the cut is its radius
                     break;
                 }
                 // Alone in its support ball: every term of the sum is exactly 0 and only the nearest
                 // neighbour (nn_dist / nn_id) is still unknown — a 2-nearest search (self + one) gives
-                // the same step as the k-list would, for a fraction of the block and no real selection.
-                if (!overflow && m == 1) {
+                // the same step as the k-list would.  The list already holds everything the block
+                // certifies, so usually it is right there.
+                if (!overflow && m_lim == 1) {
                     Kq = 2;
-                    r2 = 1; // its nearest neighbour is most likely still inside the 27 cells
+                    if (m >= 2) break; // the 2nd smallest lies inside the certified radius: done
+                    r2 = r + 1;        // nobody else in the block: grow it
                 }
                 overflow = false;
                 continue; // general path
@@ -223,9 +234,9 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
         // Quickselect with ballots.  Invariant: count(key <= lo) < Kq <= count(key <= hi); a pivot is
         // any candidate strictly inside (lo, hi).  ~2 ln m rounds expected,
         // against the 32 (fp32) / 64 (fp64) rounds a bisection over the bit pattern needs.
-        U lo = 0, hi = Bits<T>::kInf;
+        U lo = 0, hi = cs_done ? Bits<T>::of(cs_lim) : Bits<T>::kInf;
         bool lo_valid = false;
-        while (!cs_done) { // cs_done: the whole list is the answer, no selection
+        while (!cs_done) { // cs_done: everything within the support ball is the answer, no selection
             bool found = false;
             U pivot = 0;
 #pragma unroll
