@@ -69,7 +69,7 @@ def _wall(wtp_amd, n_wall):
     return b
 
 
-def _worker(rank, world, port, n_total, iters, q, margin=None, resident=False, n_wall=0):
+def _worker(rank, world, port, n_total, iters, q, margin=None, resident=False, n_wall=0, use_run=False):
     for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -88,6 +88,10 @@ def _worker(rank, world, port, n_total, iters, q, margin=None, resident=False, n
     if n_wall:   # the stop rules of _relax! over the reduced scalars: tol = 0 -> exactly `iters` sweeps
         assert len(drv.relax(max_iters=50, tol=1e30)) == 1          # |F| s < tol after the first sweep
         conv = [drv.history[0]["max_force"]] + drv.relax(max_iters=iters - 1, tol=0.0)
+    elif use_run:   # the benchmark loop: one collective per iteration, scalars reduced one phase later
+        last = drv.run(iters)
+        conv = [h["max_force"] for h in drv.history]
+        assert len(conv) == iters and last["max_force"] == conv[-1]
     else:
         conv = [drv.step()["max_force"] for _ in range(iters)]
     allp = drv.gather_global(n_total)
@@ -104,16 +108,16 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("resident", [False, True])
+@pytest.mark.parametrize("resident,use_run", [(False, False), (True, False), (True, True)])
 @pytest.mark.parametrize("world,margin", [(2, None), (3, None), (2, 0.0), (3, 0.0)])
-def test_sharded_matches_single_domain(O, wtp, world, margin, resident):
+def test_sharded_matches_single_domain(O, wtp, world, margin, resident, use_run):
     # margin=None: lazy migration (points may stray a quarter ghost width past a cut);
     # margin=0: every crossing is handed over at once, so the migration path runs every iteration
     n_total, iters = 6000, 4
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, iters, q, margin, resident))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, iters, q, margin, resident, 0, use_run))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -170,7 +174,7 @@ def test_sharded_with_a_global_wall_and_stop_rules(O, wtp, world, resident):
 
 # ---- the same logic with the PRODUCT engine: 2 ranks sharing the one GPU of the test box, payloads
 # staged through host memory because gloo carries CPU tensors (RCCL needs one GPU per rank) ----------
-def _gpu_worker(rank, world, port, n_total, iters, q, ghost_w_over_s=None, n_wall=0, margin=None):
+def _gpu_worker(rank, world, port, n_total, iters, q, ghost_w_over_s=None, n_wall=0, margin=None, use_run=False):
     for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -194,7 +198,11 @@ def _gpu_worker(rank, world, port, n_total, iters, q, ghost_w_over_s=None, n_wal
     w = sharded.ghost_width(n_total, k) if ghost_w_over_s is None else ghost_w_over_s * s
     wall = torch.from_numpy(_wall(wtp_amd, n_wall)).cuda() if n_wall else None
     drv = sharded.ShardedRelax(eng, dist, xyz, gid, cuts, w, comm_device="cpu", wall_xyz=wall, margin=margin)
-    conv = drv.relax(max_iters=iters, tol=0.0) if n_wall else [drv.step()["max_force"] for _ in range(iters)]
+    if use_run:
+        drv.run(iters)
+        conv = [h["max_force"] for h in drv.history]
+    else:
+        conv = drv.relax(max_iters=iters, tol=0.0) if n_wall else [drv.step()["max_force"] for _ in range(iters)]
     allp = drv.gather_global(n_total)
     if rank == 0:
         q.put((conv, allp.numpy(), drv.widened, drv.w / s, drv.migrations))
@@ -205,16 +213,19 @@ def _gpu_worker(rank, world, port, n_total, iters, q, ghost_w_over_s=None, n_wal
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,ghost_w_over_s,n_wall,margin", [(2, None, 0, None), (2, 0.6, 0, None), (2, None, 4000, None),
-                                                               (2, None, 0, 0.0), (3, None, 0, None)])
-def test_sharded_gpu_engine_two_ranks_one_gpu(O, wtp, world, ghost_w_over_s, n_wall, margin):
+@pytest.mark.parametrize("world,ghost_w_over_s,n_wall,margin,use_run",
+                         [(2, None, 0, None, False), (2, 0.6, 0, None, False), (2, None, 4000, None, False),
+                          (2, None, 0, 0.0, False), (3, None, 0, None, False),
+                          (2, None, 0, None, True), (2, 0.6, 0, None, True), (3, None, 0, 0.0, True)])
+def test_sharded_gpu_engine_two_ranks_one_gpu(O, wtp, world, ghost_w_over_s, n_wall, margin, use_run):
     # ghost_w_over_s = 0.6: a ghost layer thinner than the force law's support — the sweep must
     # notice (n_uncovered), and the driver must undo, widen and repeat until the answer is global
     n_total, iters = 120000, 3   # world = 3: an interior rank with two neighbours
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, n_total, iters, q, ghost_w_over_s, n_wall, margin))
+    procs = [ctx.Process(target=_gpu_worker,
+                         args=(r, world, port, n_total, iters, q, ghost_w_over_s, n_wall, margin, use_run))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -235,6 +246,6 @@ def test_sharded_gpu_engine_two_ranks_one_gpu(O, wtp, world, ghost_w_over_s, n_w
     snap = np.concatenate([_wall(wtp, n_wall), x]) if n_wall else x
     ref = O.relax_loop(snap, n_wall, s, 2, 0.2, 1.0, 3.0, 21, s / 2000, s / 20, max_iters=iters, tol=0.0, rebuild_every=1,
                        stall_after=0)
-    assert np.allclose(conv, ref["conv"], rtol=1e-3)
+    assert len(conv) == iters and np.allclose(conv, ref["conv"], rtol=1e-3)
     err = np.abs(allp - ref["p"]).max(axis=1) / s
     assert np.quantile(err, 0.999) < 1e-4 and err.max() < 1e-2

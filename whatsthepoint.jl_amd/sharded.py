@@ -163,6 +163,8 @@ class ShardedRelax:
         self._wall_local = None
         self._wall_w = None
         self._wall_set = False
+        self._deferred = None         # run(): local scalars of the last sweep, not yet reduced
+        self._rider_all = None
         self._next_layers = None      # boundary layers extracted together with the previous sweep
         self._next_layers_key = None  # ... for these planes
         self.last_local_points = int(owned_xyz.shape[0])
@@ -193,18 +195,22 @@ class ShardedRelax:
         return self._wall_local
 
     # ---- point-to-point exchange with the two slab neighbours ------------------------------------
-    def _exchange(self, to_lo: torch.Tensor, split_lo: int, to_hi: torch.Tensor, split_hi: int):
+    def _exchange(self, to_lo: torch.Tensor, split_lo: int, to_hi: torch.Tensor, split_hi: int, rider=None):
         """One round: send `to_lo` to rank-1 and `to_hi` to rank+1.  Each payload is
         [migrants ; ghost layer] with `split_*` migrants first; rows are
         [x, y, z, gid_lo_bits, gid_hi_bits] as int32 words.  Returns
-        (from_lo, n_migrants_from_lo, from_hi, n_migrants_from_hi)."""
+        (from_lo, n_migrants_from_lo, from_hi, n_migrants_from_hi).
+        rider: a few doubles that travel with the counts in the same all-gather (run() sends the previous
+        sweep's local scalars this way); every rank's copy comes back in self._rider_all."""
         d, r, W = self.dist, self.rank, self.world
         lo, hi = r - 1, r + 1
         to_lo, to_hi = to_lo.to(self.cdev), to_hi.to(self.cdev)
-        cnt_send = torch.tensor([split_lo, to_lo.shape[0], split_hi, to_hi.shape[0]], dtype=torch.int64, device=self.cdev)
-        cnt_all = [torch.zeros(4, dtype=torch.int64, device=self.cdev) for _ in range(W)]
+        head = [float(split_lo), float(to_lo.shape[0]), float(split_hi), float(to_hi.shape[0])]  # exact below 2^53
+        cnt_send = torch.tensor(head + (list(rider) if rider is not None else []), dtype=torch.float64, device=self.cdev)
+        cnt_all = [torch.zeros_like(cnt_send) for _ in range(W)]
         d.all_gather(cnt_all, cnt_send)
         cnt = torch.stack(cnt_all).cpu()
+        self._rider_all = cnt[:, 4:] if rider is not None else None
         m_from_lo, n_from_lo = (int(cnt[lo, 2]), int(cnt[lo, 3])) if lo >= 0 else (0, 0)
         m_from_hi, n_from_hi = (int(cnt[hi, 0]), int(cnt[hi, 1])) if hi < W else (0, 0)
         cols = to_lo.shape[1]
@@ -283,7 +289,11 @@ class ShardedRelax:
             lo, hi = self._bounds()
             self.engine.set_coverage(2, lo - (self.w + self.margin), hi + (self.w + self.margin))
 
-    def _step_resident(self, attempt: int = 0):
+    def _step_resident(self, attempt: int = 0, defer: bool = False):
+        """One iteration.  defer=True (run()): this sweep's scalars are not reduced right away; they ride
+        with the NEXT iteration's count exchange (one collective per iteration instead of two), so the
+        global view of sweep i — and the undo/widen/redo when it reports uncovered queries — arrives one
+        phase later, before anything of iteration i+1 has touched the state.  Returns None then."""
         eng = self.engine
         lo, hi = self._bounds()
         if not self._open:
@@ -317,7 +327,15 @@ class ShardedRelax:
                 lo_rows = torch.cat([mig_lo, self._rows4(xyz[keep & (z < lo + w_eff)])])
                 hi_rows = torch.cat([mig_hi, self._rows4(xyz[keep & (z >= hi - w_eff)])])
                 emigrants = [self._rows4(xyz[go_lo]), self._rows4(xyz[go_hi])]
-            from_lo, m_lo, from_hi, m_hi = self._exchange(lo_rows, split_lo, hi_rows, split_hi)
+            rider = self._deferred[0] if self._deferred is not None else None
+            from_lo, m_lo, from_hi, m_hi = self._exchange(lo_rows, split_lo, hi_rows, split_hi, rider=rider)
+            if rider is not None:
+                # the previous sweep, now seen globally; nothing of this iteration has touched the state yet
+                prev = self._settle(self._rider_all)
+                if prev["n_uncovered"] > 0:
+                    self._heal(prev, attempt)
+                    self._step_resident(attempt + 1, defer=True)  # the previous sweep again, wider layer
+                    return "redone"
             # 2. membership changed (someone left or arrived): restart the session on the new owned set
             if migrate or m_lo or m_hi:
                 if not migrate:
@@ -355,25 +373,58 @@ class ShardedRelax:
             self._next_layers_key = planes
         else:
             st = eng.step()
+        if defer and self.world > 1:
+            self._deferred = (self._local5(st), n_ghost, n_own, int(st.get("n_fallback", 0)))
+            return None
         out = self._reduce(st, n_ghost, n_own)
         if out["n_uncovered"] > 0:
-            # some rank's sweep needed points beyond its ghost layer (a k-th neighbour past the cover):
-            # every rank sees the same global count, so all undo the step, widen and redo it
-            if attempt >= 4 or not hasattr(eng, "revert"):
-                raise RuntimeError(f"{out['n_uncovered']} queries reach past the ghost layer (w={self.w:g})")
-            eng.revert()
-            self._next_layers = None
-            self.history.pop()
-            self.w *= 1.5
-            self.widened += 1
-            self._set_coverage()
+            self._heal(out, attempt)
             return self._step_resident(attempt + 1)
+        return out
+
+    @staticmethod
+    def _local5(st):
+        return [st["max_force"], st["sum_u"], st["sum_u2"], float(st["n_move"]), float(st.get("n_uncovered", 0))]
+
+    def _settle(self, allv):
+        """Global scalars of the deferred sweep from every rank's five doubles (W x 5, on the host)."""
+        _, n_ghost, n_own, n_fb = self._deferred
+        self._deferred = None
+        out = dict(max_force=float(allv[:, 0].max()), sum_u=float(allv[:, 1].sum()), sum_u2=float(allv[:, 2].sum()),
+                   n_move=int(allv[:, 3].sum()), n_uncovered=int(allv[:, 4].sum()), n_ghost=n_ghost, n_owned=n_own,
+                   n_fallback=n_fb)
+        self.history.append(out)
+        return out
+
+    def _heal(self, out, attempt):
+        """Some rank's sweep needed points beyond its ghost layer (a k-th neighbour past the cover): every
+        rank sees the same global count, so all undo the step and widen the layer; the caller redoes it."""
+        if attempt >= 4 or not hasattr(self.engine, "revert"):
+            raise RuntimeError(f"{out['n_uncovered']} queries reach past the ghost layer (w={self.w:g})")
+        self.engine.revert()
+        self._next_layers = None
+        self.history.pop()
+        self.w *= 1.5
+        self.widened += 1
+        self._set_coverage()
+
+    def _flush(self, attempt: int = 0):
+        """Reduce the last deferred sweep (end of run()); undo/widen/redo it if it was not covered."""
+        if self._deferred is None:
+            return self.history[-1] if self.history else None
+        mine = torch.tensor(self._deferred[0], dtype=torch.float64, device=self.cdev)
+        allv = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(allv, mine)
+        out = self._settle(torch.stack(allv).cpu())
+        if out["n_uncovered"] > 0:
+            self._heal(out, attempt)
+            self._step_resident(attempt + 1, defer=True)
+            return self._flush(attempt + 1)
         return out
 
     def _reduce(self, st, n_ghost, n_own):
         """Global stop-rule scalars (src/repel.jl:293,374-386) and the coverage count: one all-gather."""
-        mine = torch.tensor([st["max_force"], st["sum_u"], st["sum_u2"], float(st["n_move"]),
-                             float(st.get("n_uncovered", 0))], dtype=torch.float64, device=self.cdev)
+        mine = torch.tensor(self._local5(st), dtype=torch.float64, device=self.cdev)
         if self.world > 1:
             allv = [torch.zeros_like(mine) for _ in range(self.world)]
             self.dist.all_gather(allv, mine)
@@ -389,6 +440,8 @@ class ShardedRelax:
     # ---- one iteration ---------------------------------------------------------------------------------
     def step(self):
         if self.resident:
+            if self._deferred is not None:
+                self._flush()
             return self._step_resident()
         lo, hi = self._bounds()
         if self.world > 1:
@@ -441,10 +494,19 @@ class ShardedRelax:
         return self._reduce(st, n_ghost, int(new_xyz.shape[0]))
 
     def run(self, iters: int):
-        last = None
-        for _ in range(iters):
-            last = self.step()
-        return last
+        """`iters` sweeps without per-iteration stop decisions (the benchmark loop).  Resident sessions on
+        more than one rank use one collective per iteration: a sweep's scalars are reduced together with
+        the next iteration's count exchange (see _step_resident).  Returns the last sweep's global scalars."""
+        if not (self.resident and self.world > 1):
+            last = None
+            for _ in range(iters):
+                last = self.step()
+            return last
+        done = 0
+        while done < iters:
+            if self._step_resident(defer=True) != "redone":  # "redone": the turn went into repeating a sweep
+                done += 1
+        return self._flush()
 
     def relax(self, max_iters: int = 1000, tol: float = 1.0e-6, stall_after: int = 0, cv_target: float = 0.0):
         """The stop rules of _relax! (src/repel.jl:305-338) over the globally reduced scalars; every
