@@ -94,6 +94,8 @@ typedef struct wtp_step_stats {
     int64_t n_fallback;/* queries that left the 27-cell fast path (diagnostic)           */
     int64_t n_uncovered;/* sharded sessions: queries whose neighbourhood reaches past the
                           covered range (wtp_relax_set_coverage); 0 when unlimited        */
+    int64_t n_escaped; /* octree method: volume points the wall rule sent back this sweep
+                          (repel.jl:466-467); 0 without wtp_relax_set_wall                */
 } wtp_step_stats;
 
 /* ---- lifetime ------------------------------------------------------------------ */
@@ -208,6 +210,46 @@ int wtp_isinside_greens(wtp_ctx* ctx, const void* test_xyz, int64_t n, const voi
  * argument error.  sum_out: n values or NULL.  */
 int wtp_isinside_winding(wtp_ctx* ctx, const void* test_xy, int64_t n, const void* poly_xy, int64_t m,
                          int dtype, uint8_t* inside_out, void* sum_out);
+
+/* ---- triangle-mesh geometry index: the octree method of repel --------
+ * Replaces TriangleIndex(T, mesh) + the TriangleOctree queries repel makes
+ * (src/octree/triangle_octree.jl:22-31,221-277; queries :71-99,532-607; src/repel.jl:522-537).
+ * vertices: nv x 3 of dtype (the index's machine type T); triangles: nt x 3 int32, 0-based.
+ * The library derives unit face normals and the angle-weighted edge / vertex pseudonormals
+ * (keyed by exact coordinates, so triangle soup with duplicated vertices needs no welding) and
+ * builds its own search tree; one mesh per context, replaced by the next call.  */
+int wtp_mesh_set(wtp_ctx* ctx, const void* vertices, int64_t nv, const int32_t* triangles, int64_t nt,
+                 int dtype);
+int wtp_mesh_clear(wtp_ctx* ctx);
+/* nt x 3 unit face normals (zero for degenerate triangles), as doubles.  */
+int wtp_mesh_face_normals(wtp_ctx* ctx, double* normals_out);
+/* {min xyz, max xyz} of the vertices, flat axes widened (_compute_bbox_raw, :279-291).  */
+int wtp_mesh_bounds(wtp_ctx* ctx, double bbox_out[6]);
+/* Per query point (host array n x 3 of dtype, converted once to the mesh's type as the reference's
+ * seam does, results converted back); every output may be NULL:
+ *   sd_out        signed distance, negative inside (_compute_signed_distance_octree, :583-607)
+ *   tri_out       nearest triangle, 0-based; of equidistant triangles the smallest index
+ *                 (the reference keeps whichever its octree traversal meets first: unpinned)
+ *   closest_out   n x 3 closest point on that triangle (closest_point_on_triangle, geometric_utils.jl:68-136)
+ *   inside_out    isinside(p, octree) (:97-99): inside the vertex bbox and sd < 0
+ *   projected_out n x 3 _project_to_boundary(p, octree, offset) (src/repel.jl:522-537):
+ *                 closest point - offset * face normal of the landing triangle  */
+int wtp_mesh_query(wtp_ctx* ctx, const void* xyz, int64_t n, int dtype, double offset, void* sd_out,
+                   int32_t* tri_out, void* closest_out, uint8_t* inside_out, void* projected_out);
+/* Installs the wall rule _constrain_octree (src/repel.jl:448-469) on the current relax session:
+ * after every sweep a boundary point is re-projected onto the mesh (offset_dist inward) and a
+ * volume point that left the domain returns to its previous position and is flagged escaped
+ * (stats.n_escaped counts them).  The first n_boundary movable points start as boundary points
+ * (src/repel.jl:148).  The mesh must stay set until wtp_relax_end.  */
+int wtp_relax_set_wall(wtp_ctx* ctx, int64_t n_boundary, double offset_dist);
+/* Per movable point: landing triangle of its last projection (0-based, -1 never projected),
+ * boundary membership, escaped flag (cleared by this read when clear_escaped != 0: the
+ * deposition pass consumes it, src/repel.jl:486-487).  Outputs may be NULL.  */
+int wtp_relax_get_wall(wtp_ctx* ctx, int32_t* tri_out, uint8_t* is_bnd_out, uint8_t* escaped_out,
+                       int clear_escaped);
+/* Writes membership and landing triangles back after the host-side deposition pass
+ * (_deposit_escaped!, src/repel.jl:471-520, serial by design).  */
+int wtp_relax_set_wall_flags(wtp_ctx* ctx, const uint8_t* is_bnd, const int32_t* tri);
 
 /* ---- sharded sessions (no counterpart in the reference) --------------
  * One rank sweeps one spatial slab.  Its session's fixed head is the ghost layer received

@@ -262,3 +262,64 @@ def isinside_winding(test, poly):
     getattr(lib(), f"wtpo_isinside_winding_{_suf(dt)}")(
         _p(test), C.c_int64(len(test)), _p(poly), C.c_int64(len(poly)), _p(sums), _p(inside))
     return inside.astype(bool), sums
+
+
+# ---- triangle-mesh geometry index (octree repel method) ------------------------------------------
+def tri_closest(p, a, b, c):
+    """closest_point_on_triangle_feature (src/octree/geometric_utils.jl:68-136): (point, feature)."""
+    p = np.ascontiguousarray(p)
+    dt = p.dtype
+    a, b, c = (np.ascontiguousarray(v, dtype=dt) for v in (a, b, c))
+    out = np.empty(3, dtype=dt)
+    feat = C.c_int32(0)
+    getattr(lib(), f"wtpo_tri_closest_{_suf(dt)}")(_p(p), _p(a), _p(b), _p(c), _p(out), C.byref(feat))
+    return out, feat.value
+
+
+def mesh_bbox(verts):
+    """_compute_bbox_raw (src/octree/triangle_octree.jl:279-291): flat axes are widened."""
+    verts = np.asarray(verts)
+    lo, hi = verts.min(axis=0).copy(), verts.max(axis=0).copy()
+    e = max(np.finfo(verts.dtype).eps * 100, verts.dtype.type(1.0e-10))
+    flat = lo == hi
+    lo[flat] -= e
+    hi[flat] += e
+    return np.concatenate([lo, hi]).astype(verts.dtype)
+
+
+def mesh_pseudonormals(verts, tris):
+    """nt x 7 x 3: face normal, vertex 1..3 and edge 12/13/23 pseudonormals (triangle_octree.jl:221-277)."""
+    verts = _xyz(verts)
+    tris = np.ascontiguousarray(tris, dtype=np.int32)
+    pn = np.zeros((len(tris), 7, 3), dtype=verts.dtype)
+    getattr(lib(), f"wtpo_mesh_pseudonormals_{_suf(verts.dtype)}")(_p(verts), _p(tris), C.c_int64(len(tris)), _p(pn))
+    return pn
+
+
+def mesh_query(verts, tris, pts, offset=0.0):
+    """Brute-force nearest triangle per point with the canonical (d2, triangle) order, and what the
+    reference derives from it.  Points are converted to the mesh's type first (the reference's seam
+    policy, triangle_octree.jl:80-83).  Returns a dict: d2, tri (0-based), closest, feature, sd,
+    inside, projected."""
+    verts = _xyz(verts)
+    dt = verts.dtype
+    tris = np.ascontiguousarray(tris, dtype=np.int32)
+    pts = np.ascontiguousarray(np.atleast_2d(pts), dtype=dt)
+    n = len(pts)
+    d2 = np.empty(n, dtype=dt)
+    tri = np.empty(n, dtype=np.int32)
+    cp = np.empty((n, 3), dtype=dt)
+    feat = np.empty(n, dtype=np.int32)
+    L = lib()
+    getattr(L, f"wtpo_mesh_nearest_{_suf(dt)}")(
+        _p(verts), _p(tris), C.c_int64(len(tris)), _p(pts), C.c_int64(n), _p(d2), _p(tri), _p(cp), _p(feat))
+    pn = mesh_pseudonormals(verts, tris)
+    bbox = mesh_bbox(verts)
+    sd = np.empty(n, dtype=dt)
+    inside = np.empty(n, dtype=np.uint8)
+    proj = np.empty((n, 3), dtype=dt)
+    ct = C.c_float if dt == np.float32 else C.c_double
+    getattr(L, f"wtpo_mesh_classify_{_suf(dt)}")(
+        _p(pts), C.c_int64(n), _p(d2), _p(tri), _p(cp), _p(feat), _p(pn), _p(bbox), ct(offset), _p(sd), _p(inside),
+        _p(proj))
+    return dict(d2=d2, tri=tri, closest=cp, feature=feat, sd=sd, inside=inside.astype(bool), projected=proj, pn=pn)

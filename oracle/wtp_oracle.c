@@ -11,6 +11,8 @@
  *   src/repel_forces.jl:37,57-60,96-100,124-127   the four force laws
  *   src/discretization/spacings.jl:19-23,67-72,121-133   variable spacings
  *   src/isinside.jl:17-33,86-106   the isinside post-filter of repel (src/repel.jl:90)
+ *   src/octree/geometric_utils.jl:68-136, src/octree/triangle_octree.jl:71-99,221-277,532-607,
+ *   src/repel.jl:448-469,522-537   nearest triangle / signed distance / wall rule of the octree method
  * Third-party arithmetic it stands in for (source NOT in the reference tree, versions only
  * compat-bounded in Project.toml:39-45): NearestNeighbors.jl 0.4.8+ (KDTree, knn, knn!,
  * inrange), Meshes.jl 0.56/0.57 (KNearestSearch, BallSearch), Distances.jl 0.10
@@ -38,6 +40,7 @@
 #define POW powf
 #define EXP expf
 #define ATAN2 atan2f
+#define ACOS acosf
 #define REAL_EPS FLT_EPSILON
 #define REAL_MAX FLT_MAX
 #include "wtp_oracle_impl.h"
@@ -47,6 +50,7 @@
 #undef POW
 #undef EXP
 #undef ATAN2
+#undef ACOS
 #undef REAL_EPS
 #undef REAL_MAX
 
@@ -56,6 +60,7 @@
 #define POW pow
 #define EXP exp
 #define ATAN2 atan2
+#define ACOS acos
 #define REAL_EPS DBL_EPSILON
 #define REAL_MAX DBL_MAX
 #include "wtp_oracle_impl.h"
@@ -65,6 +70,7 @@
 #undef POW
 #undef EXP
 #undef ATAN2
+#undef ACOS
 #undef REAL_EPS
 #undef REAL_MAX
 

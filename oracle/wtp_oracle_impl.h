@@ -735,6 +735,204 @@ void FN(wtpo_isinside_winding)(const REAL* test, int64_t n, const REAL* poly, in
     }
 }
 
+
+/* ======================================================================================
+ * Triangle-mesh geometry index: the queries the octree repel method makes
+ * (src/repel.jl:122-181 wall rule :448-469, projection :522-537).
+ *
+ *   closest point + feature   src/octree/geometric_utils.jl:68-136 (Ericson region tests)
+ *   face normals, angle-weighted edge / vertex pseudonormals keyed by exact coordinates
+ *                             src/octree/triangle_octree.jl:221-277, :297-311
+ *   nearest triangle          :532-553 (strict d2 < best; which of two equidistant triangles wins
+ *                             depends on the octree traversal there: parity unpinned.  Canonical
+ *                             rule here: smallest (d2, triangle index), by brute force)
+ *   signed distance           :583-607 (sign of (p - closest) . pseudonormal of the closest feature)
+ *   isinside                  :71-99  (mesh bbox test, then sd < 0; the leaf-class cache of the
+ *                             reference is an accelerator for the same predicate)
+ *   project_to_boundary       src/repel.jl:522-537 (closest point - offset * face normal)
+ * Vector arithmetic is written out left to right (dot = (a1 b1 + a2 b2) + a3 b3).
+ * ====================================================================================== */
+static inline REAL FN(dot3)(const REAL* a, const REAL* b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+
+/* returns the feature code 0 face, 1..3 vertex, 4 e12, 5 e13, 6 e23 */
+static int FN(tri_closest)(const REAL* p, const REAL* a, const REAL* b, const REAL* c, REAL* out) {
+    REAL ab[3], ac[3], ap[3], bp[3], cp[3];
+    for (int i = 0; i < 3; ++i) { ab[i] = b[i] - a[i]; ac[i] = c[i] - a[i]; ap[i] = p[i] - a[i]; }
+    const REAL d1 = FN(dot3)(ab, ap), d2 = FN(dot3)(ac, ap);
+    if (d1 <= 0 && d2 <= 0) { for (int i = 0; i < 3; ++i) out[i] = a[i]; return 1; }
+    for (int i = 0; i < 3; ++i) bp[i] = p[i] - b[i];
+    const REAL d3 = FN(dot3)(ab, bp), d4 = FN(dot3)(ac, bp);
+    if (d3 >= 0 && d4 <= d3) { for (int i = 0; i < 3; ++i) out[i] = b[i]; return 2; }
+    const REAL vc = d1 * d4 - d3 * d2;
+    if (vc <= 0 && d1 >= 0 && d3 <= 0) {
+        const REAL v = d1 / (d1 - d3);
+        for (int i = 0; i < 3; ++i) out[i] = a[i] + v * ab[i];
+        return 4;
+    }
+    for (int i = 0; i < 3; ++i) cp[i] = p[i] - c[i];
+    const REAL d5 = FN(dot3)(ab, cp), d6 = FN(dot3)(ac, cp);
+    if (d6 >= 0 && d5 <= d6) { for (int i = 0; i < 3; ++i) out[i] = c[i]; return 3; }
+    const REAL vb = d5 * d2 - d1 * d6;
+    if (vb <= 0 && d2 >= 0 && d6 <= 0) {
+        const REAL w = d2 / (d2 - d6);
+        for (int i = 0; i < 3; ++i) out[i] = a[i] + w * ac[i];
+        return 5;
+    }
+    const REAL va = d3 * d6 - d5 * d4;
+    if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) {
+        const REAL w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+        for (int i = 0; i < 3; ++i) out[i] = b[i] + w * (c[i] - b[i]);
+        return 6;
+    }
+    const REAL denom = (REAL)1 / ((va + vb) + vc);
+    const REAL v = vb * denom, w = vc * denom;
+    for (int i = 0; i < 3; ++i) out[i] = (a[i] + ab[i] * v) + ac[i] * w;
+    return 0;
+}
+
+void FN(wtpo_tri_closest)(const REAL* p, const REAL* a, const REAL* b, const REAL* c, REAL* out, int32_t* feature) {
+    *feature = FN(tri_closest)(p, a, b, c, out);
+}
+
+typedef struct {
+    REAL key[6];   /* vertex: 3 coords (+3 zero); edge: the lexicographically smaller end first */
+    int64_t order; /* triangle * 3 + slot: accumulation order of the reference's loops */
+    REAL add[3];
+} FN(PnTerm);
+
+static int FN(pn_cmp)(const void* pa, const void* pb) {
+    const FN(PnTerm)* a = (const FN(PnTerm)*)pa;
+    const FN(PnTerm)* b = (const FN(PnTerm)*)pb;
+    const int c = memcmp(a->key, b->key, sizeof(a->key)); /* exact-coordinate identity (bit patterns) */
+    if (c) return c;
+    return a->order < b->order ? -1 : (a->order > b->order ? 1 : 0);
+}
+
+static int FN(lex_less)(const REAL* a, const REAL* b) { /* SVector isless: lexicographic */
+    for (int i = 0; i < 3; ++i) {
+        if (a[i] < b[i]) return 1;
+        if (a[i] > b[i]) return 0;
+    }
+    return 0;
+}
+
+static REAL FN(corner_angle)(const REAL* vc, const REAL* va, const REAL* vb) {
+    REAL u[3], w[3];
+    for (int i = 0; i < 3; ++i) { u[i] = va[i] - vc[i]; w[i] = vb[i] - vc[i]; }
+    const REAL den = SQRT(FN(dot3)(u, u) * FN(dot3)(w, w));
+    if (den < REAL_EPS) return 0;
+    REAL c = FN(dot3)(u, w) / den;
+    c = c < (REAL)-1 ? (REAL)-1 : (c > (REAL)1 ? (REAL)1 : c);
+    return ACOS(c);
+}
+
+/* pn: nt x 7 x 3 = {face, vertex 1..3, edge 12, 13, 23} pseudonormals per triangle (not normalised:
+ * only their sign against (p - closest) is used, as in the reference). */
+void FN(wtpo_mesh_pseudonormals)(const REAL* verts, const int32_t* tris, int64_t nt, REAL* pn) {
+    FN(PnTerm)* vt = (FN(PnTerm)*)calloc((size_t)(3 * nt > 0 ? 3 * nt : 1), sizeof(FN(PnTerm)));
+    FN(PnTerm)* et = (FN(PnTerm)*)calloc((size_t)(3 * nt > 0 ? 3 * nt : 1), sizeof(FN(PnTerm)));
+    for (int64_t t = 0; t < nt; ++t) {
+        const REAL* v[3] = {verts + 3 * tris[3 * t], verts + 3 * tris[3 * t + 1], verts + 3 * tris[3 * t + 2]};
+        REAL e1[3], e2[3], nr[3];
+        for (int i = 0; i < 3; ++i) { e1[i] = v[1][i] - v[0][i]; e2[i] = v[2][i] - v[0][i]; }
+        nr[0] = e1[1] * e2[2] - e1[2] * e2[1];
+        nr[1] = e1[2] * e2[0] - e1[0] * e2[2];
+        nr[2] = e1[0] * e2[1] - e1[1] * e2[0];
+        const REAL mag = SQRT(FN(dot3)(nr, nr));
+        REAL* f = pn + 21 * t;
+        for (int i = 0; i < 3; ++i) f[i] = mag < REAL_EPS * 100 ? (REAL)0 : nr[i] / mag;
+        static const int ea[3] = {0, 1, 2}, eb[3] = {1, 2, 0}; /* (v1,v2), (v2,v3), (v3,v1) */
+        for (int s = 0; s < 3; ++s) {
+            FN(PnTerm)* e = et + 3 * t + s;
+            const REAL* a = v[ea[s]];
+            const REAL* b = v[eb[s]];
+            const int ab = FN(lex_less)(a, b);
+            for (int i = 0; i < 3; ++i) { e->key[i] = ab ? a[i] : b[i]; e->key[3 + i] = ab ? b[i] : a[i]; e->add[i] = f[i]; }
+            e->order = 3 * t + s;
+            FN(PnTerm)* q = vt + 3 * t + s; /* corner s with its two neighbours in cyclic order */
+            const REAL ang = FN(corner_angle)(v[s], v[(s + 1) % 3], v[(s + 2) % 3]);
+            for (int i = 0; i < 3; ++i) { q->key[i] = v[s][i]; q->key[3 + i] = 0; q->add[i] = ang * f[i]; }
+            q->order = 3 * t + s;
+        }
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        FN(PnTerm)* terms = pass ? et : vt;
+        qsort(terms, (size_t)(3 * nt), sizeof(FN(PnTerm)), FN(pn_cmp));
+        int64_t i = 0;
+        while (i < 3 * nt) {
+            int64_t j = i;
+            REAL sum[3] = {0, 0, 0};
+            while (j < 3 * nt && memcmp(terms[j].key, terms[i].key, sizeof(terms[i].key)) == 0) {
+                for (int c = 0; c < 3; ++c) sum[c] = sum[c] + terms[j].add[c];
+                ++j;
+            }
+            for (int64_t q = i; q < j; ++q) {
+                const int64_t t = terms[q].order / 3;
+                const int s = (int)(terms[q].order % 3);
+                /* vertex slot s -> feature 1 + s; edge slots (12),(23),(31) -> features 4, 6, 5 */
+                const int feat = pass ? (s == 0 ? 4 : (s == 1 ? 6 : 5)) : 1 + s;
+                for (int c = 0; c < 3; ++c) pn[21 * t + 3 * feat + c] = sum[c];
+            }
+            i = j;
+        }
+    }
+    free(vt);
+    free(et);
+}
+
+/* Brute force over every triangle: canonical minimum of (d2, triangle index). */
+void FN(wtpo_mesh_nearest)(const REAL* verts, const int32_t* tris, int64_t nt, const REAL* pts, int64_t n,
+                           REAL* d2_out, int32_t* tri_out, REAL* cp_out, int32_t* feat_out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        const REAL* p = pts + 3 * i;
+        REAL best = REAL_MAX, bc[3] = {p[0], p[1], p[2]};
+        int32_t bt = -1, bf = 0;
+        for (int64_t t = 0; t < nt; ++t) {
+            REAL cp[3], dv[3];
+            const int f = FN(tri_closest)(p, verts + 3 * tris[3 * t], verts + 3 * tris[3 * t + 1],
+                                          verts + 3 * tris[3 * t + 2], cp);
+            for (int c = 0; c < 3; ++c) dv[c] = p[c] - cp[c];
+            const REAL d2 = FN(dot3)(dv, dv);
+            if (d2 < best) { best = d2; bt = (int32_t)t; bf = f; bc[0] = cp[0]; bc[1] = cp[1]; bc[2] = cp[2]; }
+        }
+        d2_out[i] = best;
+        tri_out[i] = bt;
+        feat_out[i] = bf;
+        for (int c = 0; c < 3; ++c) cp_out[3 * i + c] = bc[c];
+    }
+}
+
+/* sd (src/octree/triangle_octree.jl:583-607), inside (:71-99), projection (src/repel.jl:522-537)
+ * from the nearest-triangle data; bbox = {min xyz, max xyz} of the vertices (:279-291). */
+void FN(wtpo_mesh_classify)(const REAL* pts, int64_t n, const REAL* d2, const int32_t* tri, const REAL* cp,
+                            const int32_t* feat, const REAL* pn, const REAL* bbox, REAL offset, REAL* sd_out,
+                            uint8_t* inside_out, REAL* proj_out) {
+    for (int64_t i = 0; i < n; ++i) {
+        const REAL* p = pts + 3 * i;
+        if (tri[i] < 0) {
+            sd_out[i] = REAL_MAX;
+            inside_out[i] = 0;
+            for (int c = 0; c < 3; ++c) proj_out[3 * i + c] = p[c];
+            continue;
+        }
+        const REAL* nrm = pn + 21 * (int64_t)tri[i] + 3 * feat[i];
+        REAL dv[3];
+        for (int c = 0; c < 3; ++c) dv[c] = p[c] - cp[3 * i + c];
+        const REAL s = FN(dot3)(dv, nrm);
+        const REAL dist = SQRT(d2[i]);
+        const REAL sd = s < 0 ? -dist : (s > 0 ? dist : (REAL)0);
+        sd_out[i] = sd;
+        int out_of_box = 0;
+        for (int c = 0; c < 3; ++c) out_of_box |= (p[c] < bbox[c]) || (p[c] > bbox[3 + c]);
+        /* classify_point with tol 0: |sd| <= 0 is BOUNDARY, sd < 0 INTERIOR */
+        const REAL asd = sd < 0 ? -sd : sd;
+        inside_out[i] = (!out_of_box && !(asd <= 0) && sd < 0) ? 1 : 0;
+        const REAL* f = pn + 21 * (int64_t)tri[i];
+        for (int c = 0; c < 3; ++c) proj_out[3 * i + c] = cp[3 * i + c] - offset * f[c];
+    }
+}
+
 #undef KD_LEAF
 #undef KD_SLACK
 #undef FN

@@ -181,3 +181,89 @@ def test_kdtree_equals_brute_force_on_exact_lattices(O, m, dim, k, dtype):
     ok, rk = O.radius(x, r)
     ob, rb = O.radius(x, r, "brute")
     assert np.array_equal(ok, ob) and np.array_equal(rk, rb)
+
+
+# ---- triangle-mesh geometry index of the octree repel method -------------------------------------------
+def _unit_cube():
+    """OctreeTestData.unit_cube_mesh (test/testsetup.jl:34-50), 0-based."""
+    v = np.array([(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1)], dtype=np.float64)
+    t = np.array([(1, 3, 2), (1, 4, 3), (5, 6, 7), (5, 7, 8), (1, 2, 6), (1, 6, 5), (3, 4, 8), (3, 8, 7), (1, 5, 8),
+                  (1, 8, 4), (2, 3, 7), (2, 7, 6)], dtype=np.int32) - 1
+    return v, t
+
+
+def test_closest_point_on_triangle_known_answers(O):
+    """test/octree_geometric.jl:4-50."""
+    v1, v2, v3 = np.array([0.0, 0, 0]), np.array([1.0, 0, 0]), np.array([0.0, 1, 0])
+    cases = [((0.25, 0.25, 1.0), (0.25, 0.25, 0.0), 0), ((-1, -1, 0), (0, 0, 0), 1), ((2, -1, 0), (1, 0, 0), 2),
+             ((-1, 2, 0), (0, 1, 0), 3), ((0.5, -0.5, 0), (0.5, 0, 0), 4), ((-0.5, 0.5, 0), (0, 0.5, 0), 5),
+             ((0.3, 0.3, 0), (0.3, 0.3, 0), 0), ((1.0, 1.0, 0.0), (0.5, 0.5, 0.0), 6)]
+    for dt in (np.float64, np.float32):
+        for p, q, feat in cases:
+            got, f = O.tri_closest(np.array(p, dtype=dt), v1, v2, v3)
+            assert np.allclose(got, q, atol=1e-6 if dt == np.float32 else 1e-10)
+            assert f == feat
+
+
+def test_unit_cube_isinside_known_answers(O):
+    """test/octree_isinside.jl:8-12,61-63 and the pseudonormal cases :113-135."""
+    v, t = _unit_cube()
+    d = 1.0e-3
+    pts = [(0.5, 0.5, 0.5), (-0.5, 0.5, 0.5), (1.5, 0.5, 0.5), (0.3, 0.3, 0.3), (0.5, 0.5, d), (0.5, 0.5, -d),
+           (d, 0.5, d), (-d, 0.5, -d)]
+    want = [True, False, False, True, True, False, True, False]
+    c = np.array([0.5, 0.5, 0.5])
+    for corner in [(0, 0, 0), (1, 1, 1), (1, 0, 1), (0, 1, 0)]:
+        corner = np.array(corner, dtype=float)
+        out = (corner - c) / np.linalg.norm(corner - c)
+        pts += [tuple(corner - d * out), tuple(corner + d * out)]
+        want += [True, False]
+    for dt in (np.float64, np.float32):
+        r = O.mesh_query(v.astype(dt), t, np.array(pts, dtype=dt))
+        assert r["inside"].tolist() == want
+        assert np.allclose(r["sd"][:4], [-0.5, 0.5, 0.5, -0.3], atol=1e-6)
+        assert abs(r["sd"][7] - np.sqrt(2) * d) < 1e-6  # edge feature: distance to the edge x = 0, z = 0
+
+
+def test_cuboid_bbox_known_answers(O):
+    """test/octree_isinside.jl:66-104: points far outside the 20 x 7 x 3 cuboid are exterior."""
+    v, t = _unit_cube()
+    v = v * np.array([20.0, 7.0, 3.0])
+    pts = np.array([(5, 3.5, 1.5), (5, 3.5, 10), (5, 3.5, 20), (25, 3.5, 1.5), (5, 10, 1.5)], dtype=np.float64)
+    assert O.mesh_query(v, t, pts)["inside"].tolist() == [True, False, False, False, False]
+
+
+def test_mesh_projection_lands_on_the_surface(O):
+    v, t = _unit_cube()
+    rng = np.random.default_rng(5)
+    pts = rng.random((500, 3)) * 1.6 - 0.3
+    r = O.mesh_query(v, t, pts, offset=1.0e-3)
+    # closest points lie on the cube's surface; the projection sits 1e-3 inside along the face normal
+    on = np.isclose(r["closest"], 0.0, atol=1e-12) | np.isclose(r["closest"], 1.0, atol=1e-12)
+    assert on.any(axis=1).all()
+    # (a landing on an edge or a corner moves along ONE face's normal and stays on the other face's plane)
+    face = r["feature"] == 0
+    assert face.sum() > 100
+    back = O.mesh_query(v, t, r["projected"][face])
+    assert back["inside"].all() and (back["sd"] >= -1.0e-3 - 1e-9).all()
+    assert np.isclose(back["sd"], -1.0e-3, atol=1e-9).mean() > 0.9  # the rest sit closer to a neighbouring face
+    # brute-force distance against a dense sampling-free check: |p - closest| equals the box distance
+    dbox = np.linalg.norm(np.maximum(np.maximum(-pts, pts - 1.0), 0.0), axis=1)
+    inside = (pts > 0).all(axis=1) & (pts < 1).all(axis=1)
+    din = np.minimum(pts, 1 - pts).min(axis=1)
+    assert np.allclose(np.sqrt(r["d2"]), np.where(inside, din, dbox), atol=1e-12)
+    assert (r["inside"] == inside).all()
+
+
+def test_pseudonormals_of_a_closed_mesh(O):
+    """Angle-weighted vertex pseudonormals of the cube point along the corner diagonals, edge
+    pseudonormals along the face bisectors (Baerentzen & Aanaes; triangle_octree.jl:255-268)."""
+    v, t = _unit_cube()
+    pn = O.mesh_pseudonormals(v, t)
+    c = np.array([0.5, 0.5, 0.5])
+    for ti in range(len(t)):
+        for s in range(3):
+            vert = v[t[ti, s]]
+            n = pn[ti, 1 + s]
+            assert np.allclose(n / np.linalg.norm(n), (vert - c) / np.linalg.norm(vert - c), atol=1e-12)
+        assert abs(np.linalg.norm(pn[ti, 0]) - 1) < 1e-12

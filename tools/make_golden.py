@@ -58,8 +58,22 @@ def box_surface(name="box_surface"):
     np.savez_compressed(os.path.join(OUT, name), centroid=c, normal=nrm, area=a)
 
 
+def stl_mesh(stem):
+    """Welded triangle mesh (vertices float32, triangles int32 0-based) of a surface the reference's
+    tests hold (test/data/<stem>.stl; TestData.BOX_PATH etc.): the input of TriangleOctree in
+    test/repel.jl and test/octree_isinside.jl.  Data only — corners are merged by exact coordinates."""
+    path = f"/root/reference/test/data/{stem}.stl"
+    if not os.path.exists(path):
+        print(path, "not mounted: keeping the committed fixture")
+        return
+    v, t = wtp_amd.octree._weld(wtp_amd.stl.read_binary_stl(path))
+    np.savez_compressed(os.path.join(OUT, f"{stem}_mesh"), vertices=v, triangles=t)
+
+
 if __name__ == "__main__":
     box_surface()
+    stl_mesh("box")
+    stl_mesh("cavity")
     knn_case("knn_f32_3d_k21.npz", 2000, 3, np.float32, 21, False, 101)
     knn_case("knn_f32_3d_k22_self.npz", 2000, 3, np.float32, 22, True, 102)
     knn_case("knn_f64_2d_k5.npz", 1500, 2, np.float64, 5, False, 103)

@@ -15,6 +15,7 @@ from .spacings import ConstantSpacing, LogLike, BoundaryLayerSpacing
 from .repel import repel, relax
 from .metrics import metrics, spacing_metrics, spacing_fidelity_metrics
 from .inside import isinside
-from . import synth, stl
+from .octree import TriangleOctree, has_consistent_normals, signed_volume
+from . import synth, stl, octree
 
 __all__ = [n for n in dir() if not n.startswith("_")]

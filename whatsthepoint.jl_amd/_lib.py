@@ -42,6 +42,7 @@ class StepStats(C.Structure):
         ("max_force", C.c_double), ("sum_u", C.c_double), ("sum_u2", C.c_double),
         ("n_move", C.c_int64), ("argmin_i", C.c_int64), ("argmin_j", C.c_int64),
         ("argmin_r", C.c_double), ("n_fallback", C.c_int64), ("n_uncovered", C.c_int64),
+        ("n_escaped", C.c_int64),
     ]
 
 
@@ -69,6 +70,14 @@ SIGNATURES = {
     "wtp_relax_end": (_i, [_vp]),
     "wtp_relax_get_spacing": (_i, [_vp, _vp]),
     "wtp_spacing_eval": (_i, [_vp, C.POINTER(SpacingDesc), _vp, _i64, _i, _i, _vp]),
+    "wtp_mesh_set": (_i, [_vp, _vp, _i64, _vp, _i64, _i]),
+    "wtp_mesh_clear": (_i, [_vp]),
+    "wtp_mesh_face_normals": (_i, [_vp, _vp]),
+    "wtp_mesh_bounds": (_i, [_vp, _vp]),
+    "wtp_mesh_query": (_i, [_vp, _vp, _i64, _i, _d, _vp, _vp, _vp, _vp, _vp]),
+    "wtp_relax_set_wall": (_i, [_vp, _i64, _d]),
+    "wtp_relax_get_wall": (_i, [_vp, _vp, _vp, _vp, _i]),
+    "wtp_relax_set_wall_flags": (_i, [_vp, _vp, _vp]),
     "wtp_isinside_greens": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _vp, _vp]),
     "wtp_isinside_winding": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _vp, _vp]),
     "wtp_set_stream": (_i, [_vp, _vp, _i]),

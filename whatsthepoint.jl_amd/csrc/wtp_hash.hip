@@ -785,7 +785,8 @@ int launch_gen_uniform(wtp_ctx* ctx, uint64_t seed, int64_t first, int64_t n, in
 // ---- final reduction of per-block partials (fixed order => deterministic) --------------------
 __global__ void reduce_partials_kernel(const Partial* __restrict__ parts, int n_parts, int used_brick, int wave_base,
                                        int used_wave, int used_generic, const int32_t* __restrict__ fb_count,
-                                       const int32_t* __restrict__ uncovered, wtp_step_stats* __restrict__ out) {
+                                       const int32_t* __restrict__ uncovered, const int32_t* __restrict__ escaped,
+                                       wtp_step_stats* __restrict__ out) {
     __shared__ Acc sm[kThreads / 64];
     Acc acc = acc_empty();
     // only the slots this step's launches wrote (fixed order => deterministic): three ranges
@@ -816,13 +817,15 @@ __global__ void reduce_partials_kernel(const Partial* __restrict__ parts, int n_
         out->argmin_r = acc.argmin_r;
         out->n_fallback = fb_count ? *fb_count : 0;
         out->n_uncovered = uncovered ? *uncovered : 0;
+        out->n_escaped = escaped ? *escaped : 0;
     }
 }
 
 int launch_reduce_partials(wtp_ctx* ctx, const Partial* parts, int n_parts, int used_brick, int used_wave,
-                           int used_generic, const int32_t* fb_count, const int32_t* uncovered, wtp_step_stats* d_slot) {
+                           int used_generic, const int32_t* fb_count, const int32_t* uncovered, const int32_t* escaped,
+                           wtp_step_stats* d_slot) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, parts, n_parts, used_brick,
-                       brick_partials(), used_wave, used_generic, fb_count, uncovered, d_slot);
+                       brick_partials(), used_wave, used_generic, fb_count, uncovered, escaped, d_slot);
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;
 }

@@ -163,6 +163,9 @@ struct RelaxState {
     double sp_p0 = 0, sp_p1 = 0, sp_p2 = 0; // LOGLIKE / BOUNDARY_LAYER parameters
     HashView pending;        // wtp_relax_set_fixed_dev left its work to the next rebuild (see there)
     int64_t shard_extra = 0; // extra capacity of the point buffers once the fixed head gets replaced
+    bool wall_active = false; // octree method: _constrain_octree runs after every sweep (wtp_relax_set_wall)
+    double wall_offset = 0;   // inward nudge of a projected boundary point (src/repel.jl:143)
+    int64_t wall_nm = 0;      // movable points the wall arrays are sized for
     int cover_axis = -1;     // sharded session: snapshot complete for cover_lo <= coord[axis] <= cover_hi
     double cover_lo = 0, cover_hi = 0;
 };
@@ -202,6 +205,14 @@ struct wtp_ctx {
     wtp::DevBuf scratch;       // misc (relax_get staging, radius rows)
     wtp::DevBuf diag;          // diagnostic builds only
     wtp::DevBuf ins_in, ins_elems, ins_partial, ins_out; // isinside filter
+    // triangle mesh of the octree method (wtp_mesh.hip): bounding-volume tree nodes, pseudonormals
+    wtp::DevBuf mesh_nodes, mesh_pn, mesh_io;
+    int64_t mesh_nt = 0;
+    int mesh_dtype = -1;
+    double mesh_bbox[6] = {0, 0, 0, 0, 0, 0};
+    double mesh_scale = 0;
+    std::vector<double> mesh_face_host; // unit face normals (the returned boundary's normals, src/repel.jl:614)
+    wtp::DevBuf wall_flags, wall_tri;   // per movable point: is_bnd | escaped (+ counter), landing triangle
     wtp::DevBuf sp_hint;       // variable spacings: nearest tree node of each snapshot point at the last sweep
     wtp::DevBuf kd_nodes;      // variable spacings: kd-tree over the boundary points (heap order)
     int64_t kd_m = 0;          // nodes in it; the key below identifies the boundary it was built from
@@ -280,7 +291,11 @@ int launch_radius_fill(wtp_ctx* ctx, SearchArgs<T>& a, T r, const int64_t* d_off
                        int32_t* d_idx);
 int launch_reduce_partials(wtp_ctx* ctx, const Partial* parts, int n_parts, int used_brick, int used_wave,
                            int used_generic, const int32_t* fb_count, const int32_t* uncovered,
-                           wtp_step_stats* d_stats_slot);
+                           const int32_t* escaped, wtp_step_stats* d_stats_slot);
+// wall rule of the octree method (wtp_mesh.hip)
+template <typename TP>
+int launch_mesh_constrain(wtp_ctx* ctx, const Pt<TP>* old, Pt<TP>* cur, int64_t n, int64_t n_fixed, double offset,
+                          const uint8_t* is_bnd, uint8_t* escaped, int32_t* tri_idx, int32_t* n_escaped);
 template <typename T>
 int launch_unpermute(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int64_t n_fixed, int dim, T* d_xyz_out);
 template <typename T>

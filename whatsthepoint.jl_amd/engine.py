@@ -46,6 +46,7 @@ class Context:
             L.check(None, rc)
         self._h = h
         self.device = device
+        self._mesh_key = None   # identity of the mesh resident in this context (octree.py)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -149,6 +150,60 @@ class Context:
         L.check(self._h, rc)
         return (inside.astype(bool), s) if return_sum else inside.astype(bool)
 
+    # ---- triangle-mesh geometry index (octree method of repel; src/octree/triangle_octree.jl) -----
+    def mesh_set(self, vertices, triangles):
+        """vertices (nv, 3) float32/float64 = the index's machine type; triangles (nt, 3) 0-based."""
+        v = np.ascontiguousarray(vertices)
+        if v.dtype not in (np.float32, np.float64):
+            v = v.astype(np.float64)
+        t = np.ascontiguousarray(triangles, dtype=np.int32)
+        if v.ndim != 2 or v.shape[1] != 3 or t.ndim != 2 or t.shape[1] != 3:
+            raise L.WtpArgumentError("mesh needs (nv, 3) vertices and (nt, 3) triangles")
+        L.check(self._h, self._lib.wtp_mesh_set(self._h, _vp(v), len(v), _vp(t), len(t), _dtype_code(v.dtype)))
+        self._mesh_key = (len(v), len(t), v.dtype)
+        self._mesh_owner = None   # octree.py marks the TriangleOctree it uploaded
+
+    def mesh_clear(self):
+        L.check(self._h, self._lib.wtp_mesh_clear(self._h))
+        self._mesh_key = None
+        self._mesh_owner = None
+
+    def mesh_face_normals(self):
+        nt = self._mesh_key[1]
+        out = np.empty((nt, 3), dtype=np.float64)
+        L.check(self._h, self._lib.wtp_mesh_face_normals(self._h, _vp(out)))
+        return out
+
+    def mesh_bounds(self):
+        out = np.empty(6, dtype=np.float64)
+        L.check(self._h, self._lib.wtp_mesh_bounds(self._h, _vp(out)))
+        return out[:3].copy(), out[3:].copy()
+
+    def mesh_query(self, pts, offset: float = 0.0, want=("sd", "tri", "closest", "inside", "projected")):
+        """Nearest-triangle queries for (n, 3) points; returns a dict with the requested outputs."""
+        pts = _cloud(pts)
+        if pts.shape[1] != 3:
+            raise L.WtpArgumentError("mesh queries are 3-D")
+        n, dt = len(pts), pts.dtype
+        out = {}
+        if "sd" in want:
+            out["sd"] = np.empty(n, dtype=dt)
+        if "tri" in want:
+            out["tri"] = np.empty(n, dtype=np.int32)
+        if "closest" in want:
+            out["closest"] = np.empty((n, 3), dtype=dt)
+        if "inside" in want:
+            out["inside"] = np.zeros(n, dtype=np.uint8)
+        if "projected" in want:
+            out["projected"] = np.empty((n, 3), dtype=dt)
+        rc = self._lib.wtp_mesh_query(self._h, _vp(pts), n, _dtype_code(dt), float(offset), _vp(out.get("sd")),
+                                      _vp(out.get("tri")), _vp(out.get("closest")), _vp(out.get("inside")),
+                                      _vp(out.get("projected")))
+        L.check(self._h, rc)
+        if "inside" in out:
+            out["inside"] = out["inside"].astype(bool)
+        return out
+
     def set_stream(self, stream_handle=None):
         """Run the library on a caller-owned HIP stream (handle as an int; 0 = the device's default
         stream, which is torch's current stream unless the caller switched); None = own stream."""
@@ -185,7 +240,8 @@ def _law_desc(law: dict, dtype, dim: int):
 
 def _stats_dict(s: L.StepStats):
     return dict(max_force=s.max_force, sum_u=s.sum_u, sum_u2=s.sum_u2, n_move=s.n_move, argmin_i=s.argmin_i,
-                argmin_j=s.argmin_j, argmin_r=s.argmin_r, n_fallback=s.n_fallback, n_uncovered=s.n_uncovered)
+                argmin_j=s.argmin_j, argmin_r=s.argmin_r, n_fallback=s.n_fallback, n_uncovered=s.n_uncovered,
+                n_escaped=s.n_escaped)
 
 
 class RelaxSession:
@@ -281,6 +337,29 @@ class RelaxSession:
         if sp.shape != (self.n,):
             raise L.WtpArgumentError("per-point spacing needs one value per snapshot point")
         L.check(self.ctx._h, self._lib.wtp_relax_set_spacing(self.ctx._h, _vp(sp)))
+
+    # ---- wall rule of the octree method (src/repel.jl:448-469) ----------------------------------
+    def set_wall(self, n_boundary: int, offset_dist: float):
+        """After every sweep: boundary points are re-projected onto the context's mesh, volume points
+        that left the domain return to their previous position (stats['n_escaped'])."""
+        L.check(self.ctx._h, self._lib.wtp_relax_set_wall(self.ctx._h, int(n_boundary), float(offset_dist)))
+
+    def get_wall(self, clear_escaped: bool = False):
+        m = self.n - self.n_fixed
+        tri = np.empty(m, dtype=np.int32)
+        is_bnd = np.empty(m, dtype=np.uint8)
+        esc = np.empty(m, dtype=np.uint8)
+        L.check(self.ctx._h, self._lib.wtp_relax_get_wall(self.ctx._h, _vp(tri), _vp(is_bnd), _vp(esc),
+                                                          int(bool(clear_escaped))))
+        return dict(tri=tri, is_bnd=is_bnd.astype(bool), escaped=esc.astype(bool))
+
+    def set_wall_flags(self, is_bnd, tri):
+        m = self.n - self.n_fixed
+        b = np.ascontiguousarray(is_bnd, dtype=np.uint8)
+        t = np.ascontiguousarray(tri, dtype=np.int32)
+        if b.shape != (m,) or t.shape != (m,):
+            raise L.WtpArgumentError("wall flags need one entry per movable point")
+        L.check(self.ctx._h, self._lib.wtp_relax_set_wall_flags(self.ctx._h, _vp(b), _vp(t)))
 
     # ---- sharded sessions (SURVEY.md §8e) ------------------------------------------------------
     def layers_dev(self, axis: int, lo_in: float, hi_in: float, lo_out: float, hi_out: float, d_lo_ptr: int,

@@ -4,8 +4,10 @@ The sweep (k-NN rebuild + force + step + reductions) runs on the GPU through lib
 module keeps what the reference keeps on the calling thread: defaults, argument checks, the stop
 rules of src/repel.jl:305-334, the kick (:415-433) and the closest-pair trace (:294-296).
 The `isinside` post-filter (src/repel.jl:90) runs on the GPU as well (inside.py); the cull
-(:91-93) takes its candidate pairs from the device radius search.  Out of scope here
-(SURVEY.md §8f): the octree wall rule (:448-537)."""
+(:91-93) takes its candidate pairs from the device radius search.  The octree method
+(:122-181) installs the wall rule _constrain_octree (:448-469) on the session: projection of the
+boundary points and the inside test of the volume points run on the GPU after every sweep
+(csrc/wtp_mesh.hip); the cloud is rebuilt here (_reconstruct_cloud, :590-629)."""
 from __future__ import annotations
 
 import logging
@@ -39,9 +41,12 @@ def _spacing_values(spacing, pts):
 
 def relax(p, snap_fixed, spacing, force_model, *, alpha_lo, alpha_max, k=21, max_iters=1000, tol=1e-6,
           rebuild_every=1, kick_after=0, stall_after=0, cv_target=0.0, trace=None, n_protected=None,
-          rng=None, ctx=None):
+          rng=None, ctx=None, wall=None):
     """_relax! (src/repel.jl:202-339).  p: movable points (n_move x dim); snap_fixed: the static
-    head of the search snapshot (may be empty).  Returns (p_final, conv list)."""
+    head of the search snapshot (may be empty).  Returns (p_final, conv list).
+    wall = dict(octree=, n_boundary=, offset=, deposit=None): the octree method's `constrain`
+    (src/repel.jl:150-152); on return wall['tri'] / wall['is_bnd'] hold the landing triangles and
+    the membership of the movable points."""
     if rebuild_every < 1:
         raise WtpArgumentError("rebuild_every must be ≥ 1")  # src/repel.jl:74
     ctx = ctx or default_context()
@@ -66,6 +71,9 @@ def relax(p, snap_fixed, spacing, force_model, *, alpha_lo, alpha_max, k=21, max
     sess = ctx.relax(snap, n_fixed, spacing.desc() if on_device else (sp if const else spacings), force_model.desc(),
                      k, alpha_lo, alpha_max)
     try:
+        if wall is not None:
+            wall["octree"]._resident(ctx)
+            sess.set_wall(wall["n_boundary"], wall["offset"])
         i = 1
         while i <= max_iters:
             rebuild = (i - 1) % rebuild_every == 0
@@ -103,6 +111,8 @@ def relax(p, snap_fixed, spacing, force_model, *, alpha_lo, alpha_max, k=21, max
                         log.info("Node repel stopped in %d iterations: spacing CV stalled for %d iterations",
                                  i, stall_after)
                         break
+            if wall is not None and wall.get("deposit") is not None:
+                wall["deposit"](sess, st, i)  # deposit!(p, method, i) :329
             if conv[-1] < tol:
                 log.info("Node repel finished in %d iterations", i)
                 break
@@ -110,6 +120,8 @@ def relax(p, snap_fixed, spacing, force_model, *, alpha_lo, alpha_max, k=21, max
         if i > max_iters:
             log.warning("Node repel reached maximum iterations (%d), convergence=%g", max_iters, conv[-1])
         out = sess.positions()
+        if wall is not None:
+            wall.update(sess.get_wall())
     finally:
         sess.close()
     return out, conv
@@ -171,14 +183,82 @@ def cull(pts, spacing, ratio, ctx=None):
     return keep
 
 
-def repel(cloud: PointCloud, spacing, *, beta=0.2, force_model: RepelForceModel = None, alpha=None,
+def _repel_octree(cloud, spacing, octree, *, force_model, alpha, alpha_min, k, max_iters, tol, rebuild_every,
+                  cull_ratio, kick_after, stall_after, cv_target, deposit_ratio, convergence, trace, ctx):
+    """repel(cloud, spacing, octree; kwargs...) (src/repel.jl:122-181): all points move, boundary points
+    are re-projected onto the mesh every iteration, escaped volume points bounce back."""
+    if deposit_ratio < 0:
+        raise WtpArgumentError("deposit_ratio must be ≥ 0")
+    if deposit_ratio > 0:
+        raise NotImplementedError("deposit_ratio > 0 (_deposit_escaped!, src/repel.jl:471-520) is not built yet")
+    all_p = cloud.points()
+    if all_p.shape[1] != 3:
+        raise WtpArgumentError("the octree method is 3-D")
+    n_boundary = len(cloud.boundary)
+    if alpha is None:
+        sv, const = _spacing_values(spacing, all_p)
+        alpha = (sv if const else float(np.min(sv))) / 20
+    if alpha_min is None:
+        alpha_min = alpha / 100
+    diag = (octree.bbox_max - octree.bbox_min).astype(octree.dtype)
+    offset = float(octree.dtype.type(1.0e-6) * np.sqrt((diag * diag).sum(dtype=octree.dtype)))  # :143
+    wall = dict(octree=octree, n_boundary=n_boundary, offset=offset, deposit=None)
+    p, conv = relax(np.array(all_p, copy=True), np.zeros((0, 3), dtype=all_p.dtype), spacing, force_model,
+                    alpha_lo=alpha_min, alpha_max=alpha, k=k, max_iters=max_iters, tol=tol,
+                    rebuild_every=rebuild_every, kick_after=kick_after, stall_after=stall_after,
+                    cv_target=cv_target, trace=trace, n_protected=n_boundary, ctx=ctx, wall=wall)
+    if convergence is not None:
+        convergence.extend(conv)
+    keep = cull(p, spacing, cull_ratio, ctx=ctx) if cull_ratio > 0 and len(p) else np.ones(len(p), dtype=bool)
+    if "is_bnd" not in wall:   # no sweep ran (max_iters < 1 or an empty cloud)
+        wall["is_bnd"] = np.arange(len(p)) < n_boundary
+        wall["tri"] = np.full(len(p), -1, dtype=np.int32)
+    return _reconstruct_cloud(cloud, p, wall["tri"], wall["is_bnd"], n_boundary, octree, spacing, keep, ctx)
+
+
+def _reconstruct_cloud(cloud, p, tri, is_bnd, n_boundary, octree, spacing, keep, ctx=None):
+    """_reconstruct_cloud (src/repel.jl:590-629): kept points split by membership into one :boundary
+    surface and the volume; projected boundary points take their landing triangle's normal, imported
+    ones keep their area, deposited ones get spacing²."""
+    from .cloud import PointBoundary, PointSurface
+
+    el = cloud.boundary.elements()
+    face = octree.face_normals(ctx)
+    ids = np.nonzero(keep & is_bnd)[0]
+    bp = p[ids]
+    normals = np.zeros((len(ids), 3), dtype=p.dtype)
+    landed = tri[ids] >= 0
+    normals[landed] = face[tri[ids][landed]].astype(p.dtype)
+    if el is not None:
+        orig = ~landed & (ids < n_boundary)
+        normals[orig] = el[1][ids[orig]]
+    areas = np.zeros(len(ids), dtype=p.dtype)
+    imported = ids < n_boundary
+    if el is not None:
+        areas[imported] = el[2][ids[imported]]
+    if (~imported).any() or el is None:
+        fresh = ~imported if el is not None else np.ones(len(ids), dtype=bool)
+        sv, const = _spacing_values(spacing, bp[fresh])
+        areas[fresh] = (sv if const else np.asarray(sv)) ** 2
+    surf = PointSurface(bp, normals, areas)
+    vol = p[keep & ~is_bnd]
+    return PointCloud(PointBoundary(surfaces={"boundary": surf}), PointVolume(vol), T.NoTopology())
+
+
+def repel(cloud: PointCloud, spacing, octree=None, *, beta=0.2, force_model: RepelForceModel = None, alpha=None,
           alpha_min=None, k=21, max_iters=1000, tol=1.0e-6, rebuild_every=1, cull_ratio=0.0, kick_after=0,
-          stall_after=50, cv_target=0.0, convergence=None, trace=None, inside=None, ctx=None):
+          stall_after=50, cv_target=0.0, deposit_ratio=0.0, convergence=None, trace=None, inside=None, ctx=None):
     """repel(cloud, spacing; kwargs...) — volume points move, boundary points are the fixed wall
-    (src/repel.jl:56-95).  Returns a new cloud with NoTopology."""
+    (src/repel.jl:56-95); repel(cloud, spacing, octree; kwargs...) — every point moves under the
+    octree wall rule (:122-181).  Returns a new cloud with NoTopology."""
     if rebuild_every < 1:
         raise WtpArgumentError("rebuild_every must be ≥ 1")
     force_model = force_model or ClippedSpacingForce(beta)
+    if octree is not None:
+        return _repel_octree(cloud, spacing, octree, force_model=force_model, alpha=alpha, alpha_min=alpha_min, k=k,
+                             max_iters=max_iters, tol=tol, rebuild_every=rebuild_every, cull_ratio=cull_ratio,
+                             kick_after=kick_after, stall_after=stall_after, cv_target=cv_target,
+                             deposit_ratio=deposit_ratio, convergence=convergence, trace=trace, ctx=ctx)
     bnd_p = cloud.boundary.points()
     p = np.array(cloud.volume.points(), copy=True)
     allp = cloud.points()
