@@ -466,7 +466,7 @@ WTP_API int wtp_destroy(wtp_ctx* ctx) {
                       &ctx->nn_id, &ctx->spacing_pp, &ctx->partials, &ctx->stats, &ctx->fb_list,
                       &ctx->fb_count, &ctx->fb2_list, &ctx->fb2_count, &ctx->scratch, &ctx->diag,
                       &ctx->ins_in, &ctx->ins_elems, &ctx->ins_partial, &ctx->ins_out, &ctx->mesh_nodes, &ctx->mesh_pn, &ctx->mesh_io,
-                      &ctx->wall_flags, &ctx->wall_tri, &ctx->kd_nodes, &ctx->sp_hint, &ctx->occ, &ctx->box_dev,
+                      &ctx->wall_flags, &ctx->wall_tri, &ctx->wall_hint, &ctx->mesh_cls, &ctx->kd_nodes, &ctx->sp_hint, &ctx->occ, &ctx->box_dev,
                       &ctx->cand_idx, &ctx->cand_dist, &ctx->f32_pts};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
@@ -906,7 +906,7 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
     if (r.wall_active) { // p[id] = constrain(id, x_i, x_i + disp) (src/repel.jl:290): the octree wall rule
         char* wf = (char*)ctx->wall_flags.p;
         rc = launch_mesh_constrain<T>(ctx, a.query, a.out, r.n, r.n_fixed, r.wall_offset, (const uint8_t*)wf,
-                                      (uint8_t*)wf + r.wall_nm, (int32_t*)ctx->wall_tri.p,
+                                      (uint8_t*)wf + r.wall_nm, (int32_t*)ctx->wall_tri.p, (int32_t*)ctx->wall_hint.p,
                                       (int32_t*)ctx->fb_count.p + 12);
         if (rc) return rc;
     }

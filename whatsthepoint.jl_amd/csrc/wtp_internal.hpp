@@ -213,6 +213,11 @@ struct wtp_ctx {
     double mesh_scale = 0;
     std::vector<double> mesh_face_host; // unit face normals (the returned boundary's normals, src/repel.jl:614)
     wtp::DevBuf wall_flags, wall_tri;   // per movable point: is_bnd | escaped (+ counter), landing triangle
+    wtp::DevBuf wall_hint;              // per movable point: tree node of its nearest triangle at the last sweep
+    wtp::DevBuf mesh_cls;               // inside/outside class per cell of a uniform grid over the mesh bbox
+    bool mesh_cls_ready = false;
+    int mesh_cls_dim[3] = {0, 0, 0};
+    double mesh_cls_cell = 0;
     wtp::DevBuf sp_hint;       // variable spacings: nearest tree node of each snapshot point at the last sweep
     wtp::DevBuf kd_nodes;      // variable spacings: kd-tree over the boundary points (heap order)
     int64_t kd_m = 0;          // nodes in it; the key below identifies the boundary it was built from
@@ -295,7 +300,7 @@ int launch_reduce_partials(wtp_ctx* ctx, const Partial* parts, int n_parts, int 
 // wall rule of the octree method (wtp_mesh.hip)
 template <typename TP>
 int launch_mesh_constrain(wtp_ctx* ctx, const Pt<TP>* old, Pt<TP>* cur, int64_t n, int64_t n_fixed, double offset,
-                          const uint8_t* is_bnd, uint8_t* escaped, int32_t* tri_idx, int32_t* n_escaped);
+                          const uint8_t* is_bnd, uint8_t* escaped, int32_t* tri_idx, int32_t* hint, int32_t* n_escaped);
 template <typename T>
 int launch_unpermute(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int64_t n_fixed, int dim, T* d_xyz_out);
 template <typename T>

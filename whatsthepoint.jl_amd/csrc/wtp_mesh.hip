@@ -294,6 +294,16 @@ __device__ inline int tri_closest(const T* p, const T* a, const T* b, const T* c
     return 0;
 }
 
+#ifdef WTP_MESH_COUNT
+__device__ unsigned long long g_mesh_count[4];
+extern "C" int wtp_mesh_count(unsigned long long out[4]) {
+    unsigned long long z[4] = {0, 0, 0, 0};
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mesh_count), sizeof(z));
+    hipMemcpyToSymbol(HIP_SYMBOL(g_mesh_count), z, sizeof(z));
+    return 0;
+}
+#endif
+
 template <typename T> struct Nearest {
     T d2;
     T cp[3];
@@ -305,26 +315,148 @@ template <typename T> __device__ inline T prune_limit(T best, T delta) {
     return best + ((T)4 * delta) * (wsqrt(best) + delta);
 }
 
-// Packet traversal (all 64 lanes of the wave call this together; inactive lanes never ask for a subtree).
+// squared distance from q to the bounding box of triangle v[9] (a lower bound of the distance to it)
+template <typename T> __device__ inline T tri_box_d2(const T* v, const T* q) {
+    T t[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        T lo = v[a] < v[3 + a] ? v[a] : v[3 + a], hi = v[a] < v[3 + a] ? v[3 + a] : v[a];
+        lo = lo < v[6 + a] ? lo : v[6 + a];
+        hi = hi > v[6 + a] ? hi : v[6 + a];
+        const T below = lo - q[a], above = q[a] - hi;
+        const T mm = below > above ? below : above;
+        t[a] = mm > (T)0 ? mm : (T)0;
+    }
+    return (t[0] * t[0] + t[1] * t[1]) + t[2] * t[2];
+}
+
+// next node in pre-order after skipping the subtree of i (1-based heap index of a left-balanced tree of
+// m nodes); 1 = walk finished
+__device__ inline uint32_t heap_escape(uint32_t i, uint32_t m) {
+    do {
+        const uint32_t j = i + 1;
+        i = j >> __builtin_ctz(j);
+    } while (i > m);
+    return i;
+}
+
+// Per-lane walk for a query that brings a good first guess (the tree node of its nearest triangle at the
+// last sweep).  The packet walk below visits the UNION of what 64 lanes want — measured 98 node steps
+// per wave on the box surface although a lane with a tight bound wants ~30 — so with a guess every lane
+// walks alone: stackless (pre-order with arithmetic skips in the heap-ordered tree), own triangle of a
+// node evaluated only if its bbox is within the bound.  Same candidates, same (d2, index) minimum.
 template <typename T>
-__device__ inline Nearest<T> mesh_nearest(const MeshNode<T>* __restrict__ nodes, int32_t m, const T* q, bool active,
-                                          T scale, int32_t* __restrict__ stack /* LDS row of this wave */) {
+__device__ inline Nearest<T> mesh_nearest_guess(const MeshNode<T>* __restrict__ nodes, int32_t m, const T* q, bool active,
+                                                T scale, int32_t guess, int32_t* best_node) {
     Nearest<T> r;
     r.d2 = Lim<T>::inf();
     r.cp[0] = q[0], r.cp[1] = q[1], r.cp[2] = q[2];
     r.tri = -1;
     r.feat = 0;
+    int32_t bn = -1;
+    if (active) {
+        T aq = q[0] < 0 ? -q[0] : q[0];
+        const T ay = q[1] < 0 ? -q[1] : q[1], az = q[2] < 0 ? -q[2] : q[2];
+        aq = aq > ay ? aq : ay;
+        aq = aq > az ? aq : az;
+        const T delta = (T)64 * EpsOf<T>::v * (aq > scale ? aq : scale);
+        T limit;
+        {
+            T v[9], cp[3], dv[3];
+#pragma unroll
+            for (int a = 0; a < 9; ++a) v[a] = nodes[guess].v[a];
+            r.feat = tri_closest<T>(q, v, v + 3, v + 6, cp);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) dv[a] = q[a] - cp[a];
+            r.d2 = ddot(dv, dv);
+            r.tri = nodes[guess].tri_axis & 0x3fffffff;
+            r.cp[0] = cp[0], r.cp[1] = cp[1], r.cp[2] = cp[2];
+            bn = guess;
+            limit = prune_limit<T>(r.d2, delta);
+        }
+        uint32_t i = 1;
+        do {
+            const MeshNode<T>& nd = nodes[i - 1];
+            T t[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const T below = nd.lo[a] - q[a], above = q[a] - nd.hi[a];
+                const T mm = below > above ? below : above;
+                t[a] = mm > (T)0 ? mm : (T)0;
+            }
+            if (((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2]) <= limit) {
+                T v[9];
+#pragma unroll
+                for (int a = 0; a < 9; ++a) v[a] = nd.v[a];
+                if ((int32_t)(i - 1) != guess && tri_box_d2<T>(v, q) <= limit) {
+                    T cp[3], dv[3];
+                    const int f = tri_closest<T>(q, v, v + 3, v + 6, cp);
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) dv[a] = q[a] - cp[a];
+                    const T d2 = ddot(dv, dv);
+                    const int32_t tri = nd.tri_axis & 0x3fffffff;
+                    if (d2 < r.d2 || (d2 == r.d2 && tri < r.tri)) {
+                        r.d2 = d2;
+                        r.tri = tri;
+                        r.feat = f;
+                        r.cp[0] = cp[0], r.cp[1] = cp[1], r.cp[2] = cp[2];
+                        bn = (int32_t)(i - 1);
+                        limit = prune_limit<T>(d2, delta);
+                    }
+                }
+                i = 2 * i <= (uint32_t)m ? 2 * i : heap_escape(i, (uint32_t)m);
+            } else {
+                i = heap_escape(i, (uint32_t)m);
+            }
+        } while (i != 1);
+    }
+    *best_node = bn;
+    return r;
+}
+
+// Packet traversal (all 64 lanes of the wave call this together; inactive lanes never ask for a subtree).
+template <typename T>
+__device__ inline Nearest<T> mesh_nearest(const MeshNode<T>* __restrict__ nodes, int32_t m, const T* q, bool active,
+                                          T scale, int32_t* __restrict__ stack /* LDS row of this wave */,
+                                          int32_t hint = -1, int32_t* best_node = nullptr) {
+    Nearest<T> r;
+    r.d2 = Lim<T>::inf();
+    r.cp[0] = q[0], r.cp[1] = q[1], r.cp[2] = q[2];
+    r.tri = -1;
+    r.feat = 0;
+    int32_t bn = -1;
     T aq = q[0] < 0 ? -q[0] : q[0];
     const T ay = q[1] < 0 ? -q[1] : q[1], az = q[2] < 0 ? -q[2] : q[2];
     aq = aq > ay ? aq : ay;
     aq = aq > az ? aq : az;
     const T delta = (T)64 * EpsOf<T>::v * (aq > scale ? aq : scale);
     T limit = active ? Lim<T>::inf() : (T)-1; // box distance >= 0 > -1
+    if (active && hint >= 0 && hint < m) { // the nearest triangle of the last sweep: a point moves a fraction of a
+        const MeshNode<T>& hn = nodes[hint]; // spacing per sweep, so this already prunes nearly every subtree
+        T v[9];
+#pragma unroll
+        for (int a = 0; a < 9; ++a) v[a] = hn.v[a];
+        T cp[3], dv[3];
+        r.feat = tri_closest<T>(q, v, v + 3, v + 6, cp);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) dv[a] = q[a] - cp[a];
+        r.d2 = ddot(dv, dv);
+        r.tri = hn.tri_axis & 0x3fffffff;
+        r.cp[0] = cp[0], r.cp[1] = cp[1], r.cp[2] = cp[2];
+        bn = hint;
+        limit = prune_limit<T>(r.d2, delta);
+    }
     int sp = 0;
     int32_t node = 0;
+#ifdef WTP_MESH_COUNT
+    int steps = 0, evals = 0;
+#endif
     for (;;) {
         node = __builtin_amdgcn_readfirstlane(node);
         const MeshNode<T> nd = nodes[node];
+#ifdef WTP_MESH_COUNT
+        ++steps;
+#endif
         T t[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -335,8 +467,11 @@ __device__ inline Nearest<T> mesh_nearest(const MeshNode<T>* __restrict__ nodes,
         const bool want = ((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2]) <= limit;
         bool descended = false;
         if (__any(want)) {
+#ifdef WTP_MESH_COUNT
+            ++evals;
+#endif
             const int32_t tri = nd.tri_axis & 0x3fffffff, sd = (nd.tri_axis >> 30) & 3;
-            if (want) {
+            if (want && tri_box_d2<T>(nd.v, q) <= limit) { // the node's own triangle may be far although its subtree is near
                 T cp[3], dv[3];
                 const int f = tri_closest<T>(q, nd.v, nd.v + 3, nd.v + 6, cp);
 #pragma unroll
@@ -347,6 +482,7 @@ __device__ inline Nearest<T> mesh_nearest(const MeshNode<T>* __restrict__ nodes,
                     r.tri = tri;
                     r.feat = f;
                     r.cp[0] = cp[0], r.cp[1] = cp[1], r.cp[2] = cp[2];
+                    bn = node;
                     limit = prune_limit<T>(d2, delta);
                 }
             }
@@ -369,6 +505,15 @@ __device__ inline Nearest<T> mesh_nearest(const MeshNode<T>* __restrict__ nodes,
             node = stack[--sp];
         }
     }
+#ifdef WTP_MESH_COUNT
+    if (best_node && (threadIdx.x & 63) == 0) {
+        atomicAdd(g_mesh_count, (unsigned long long)steps);
+        atomicAdd(g_mesh_count + 1, (unsigned long long)evals);
+        atomicAdd(g_mesh_count + 2, 1ull);
+        atomicMax(g_mesh_count + 3, (unsigned long long)steps);
+    }
+#endif
+    if (best_node) *best_node = bn;
     return r;
 }
 
@@ -378,7 +523,26 @@ template <typename T> struct MeshView {
     int32_t m;
     T lo[3], hi[3]; // vertex bbox (classify_point's fast path)
     T scale;        // largest |coordinate| of the mesh
+    // inside/outside class per cell of a uniform grid over the bbox (the role of the reference's
+    // leaf_classification cache, src/octree/triangle_octree.jl:84-89): 0 = near the surface (exact
+    // test), 1 = wholly inside, 2 = wholly outside.  nullptr: every point takes the exact test.
+    const uint8_t* cls;
+    int32_t cdim[3];
+    T cinv; // 1 / cell edge
 };
+
+enum : uint8_t { CLS_BOUNDARY = 0, CLS_INTERIOR = 1, CLS_EXTERIOR = 2 };
+
+template <typename T> __device__ inline uint8_t cell_class(const MeshView<T>& mv, const T* q) {
+    int64_t c[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        int32_t i = (int32_t)((q[a] - mv.lo[a]) * mv.cinv);
+        i = i < 0 ? 0 : (i >= mv.cdim[a] ? mv.cdim[a] - 1 : i);
+        c[a] = i;
+    }
+    return mv.cls[(c[2] * mv.cdim[1] + c[1]) * mv.cdim[0] + c[0]];
+}
 
 // sign of (p - closest) . pseudonormal(feature): < 0 inside
 template <typename T> __device__ inline T side_of(const MeshView<T>& mv, const T* q, const Nearest<T>& r) {
@@ -393,6 +557,32 @@ template <typename T> __device__ inline bool in_bbox(const MeshView<T>& mv, cons
 #pragma unroll
     for (int a = 0; a < 3; ++a) out = out || (q[a] < mv.lo[a]) || (q[a] > mv.hi[a]);
     return !out;
+}
+
+// One exact signed distance per cell centre.  A point of the cell is at most half a diagonal from the
+// centre, so if the surface is farther than that (plus rounding slack) no point of the cell can be
+// on the other side of it.
+template <typename T>
+__global__ void __launch_bounds__(kMeshThreads)
+mesh_classify_kernel(MeshView<T> mv, T cell, int64_t ncell, uint8_t* __restrict__ cls) {
+    __shared__ int32_t stk[kMeshThreads / 64][64];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t span = (ncell + 63) / 64 * 64;
+    const T half_diag = wsqrt((T)0.75) * cell;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < span; i += stride) {
+        const bool active = i < ncell;
+        const int64_t ii = active ? i : ncell - 1;
+        const int64_t cx = ii % mv.cdim[0], cy = (ii / mv.cdim[0]) % mv.cdim[1], cz = ii / ((int64_t)mv.cdim[0] * mv.cdim[1]);
+        const T q[3] = {mv.lo[0] + ((T)cx + (T)0.5) * cell, mv.lo[1] + ((T)cy + (T)0.5) * cell,
+                        mv.lo[2] + ((T)cz + (T)0.5) * cell};
+        const Nearest<T> r = mesh_nearest<T>(mv.nodes, mv.m, q, active, mv.scale, stk[threadIdx.x >> 6]);
+        if (!active) continue;
+        const T s = side_of<T>(mv, q, r);
+        const T slack = half_diag * (T)1.001 + (T)256 * EpsOf<T>::v * mv.scale;
+        uint8_t c = CLS_BOUNDARY;
+        if (wsqrt(r.d2) > slack) c = s < (T)0 ? CLS_INTERIOR : (s > (T)0 ? CLS_EXTERIOR : CLS_BOUNDARY);
+        cls[i] = c;
+    }
 }
 
 // Raw AoS points -> any of {signed distance, triangle, closest point, inside flag, projection}.
@@ -431,7 +621,7 @@ template <typename TM, typename TP>
 __global__ void __launch_bounds__(kMeshThreads)
 mesh_constrain_kernel(const Pt<TP>* __restrict__ old, Pt<TP>* __restrict__ cur, int64_t n, int32_t n_fixed,
                       MeshView<TM> mv, TM offset, const uint8_t* __restrict__ is_bnd, uint8_t* __restrict__ escaped,
-                      int32_t* __restrict__ tri_idx, int32_t* __restrict__ n_escaped) {
+                      int32_t* __restrict__ tri_idx, int32_t* __restrict__ hint, int32_t* __restrict__ n_escaped) {
     __shared__ int32_t stk[kMeshThreads / 64][64];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t span = (n + 63) / 64 * 64;
@@ -444,10 +634,28 @@ mesh_constrain_kernel(const Pt<TP>* __restrict__ old, Pt<TP>* __restrict__ cur, 
         const bool bnd = active && is_bnd[id - n_fixed] != 0;
         // a volume point outside the mesh bbox is outside without a search (classify_point's fast path)
         const bool boxed = in_bbox<TM>(mv, q);
-        const bool search = active && (bnd || boxed);
+        // ... and one whose grid cell lies wholly on one side of the surface needs none either
+        const uint8_t cls = (active && !bnd && boxed && mv.cls) ? cell_class<TM>(mv, q) : (uint8_t)CLS_BOUNDARY;
+        const bool search = active && (bnd || (boxed && cls == CLS_BOUNDARY));
         Nearest<TM> r;
         r.tri = -1;
-        if (__any(search)) r = mesh_nearest<TM>(mv.nodes, mv.m, q, search, mv.scale, stk[threadIdx.x >> 6]);
+        r.d2 = (TM)1;
+        if (__any(search)) {
+            const int32_t g = search ? hint[id - n_fixed] : -1;
+            const bool guessed = search && g >= 0 && g < mv.m;
+            int32_t bn = -1;
+            if (__any(guessed)) r = mesh_nearest_guess<TM>(mv.nodes, mv.m, q, guessed, mv.scale, g, &bn);
+            if (__any(search && !guessed)) { // first sweep, or a point that just came near the surface
+                int32_t bn2 = -1;
+                const Nearest<TM> r2 =
+                    mesh_nearest<TM>(mv.nodes, mv.m, q, search && !guessed, mv.scale, stk[threadIdx.x >> 6], -1, &bn2);
+                if (search && !guessed) {
+                    r = r2;
+                    bn = bn2;
+                }
+            }
+            if (search) hint[id - n_fixed] = bn;
+        }
         if (!active) continue;
         if (bnd) {
             const TM* f = mv.pn + 21 * (int64_t)r.tri;
@@ -459,7 +667,7 @@ mesh_constrain_kernel(const Pt<TP>* __restrict__ old, Pt<TP>* __restrict__ cur, 
             tri_idx[id - n_fixed] = r.tri;
         } else {
             bool inside = false;
-            if (boxed) inside = side_of<TM>(mv, q, r) < (TM)0 && r.d2 > (TM)0;
+            if (boxed) inside = cls == CLS_INTERIOR || (cls == CLS_BOUNDARY && side_of<TM>(mv, q, r) < (TM)0 && r.d2 > (TM)0);
             if (!inside) {
                 const Pt<TP> xo = old[i];
                 Pt<TP> o = p;
@@ -487,6 +695,9 @@ template <typename TM> static MeshView<TM> make_view(const wtp_ctx* ctx) {
         mv.hi[a] = (TM)ctx->mesh_bbox[3 + a];
     }
     mv.scale = (TM)ctx->mesh_scale;
+    mv.cls = ctx->mesh_cls_ready ? (const uint8_t*)ctx->mesh_cls.p : nullptr;
+    for (int a = 0; a < 3; ++a) mv.cdim[a] = ctx->mesh_cls_dim[a];
+    mv.cinv = (TM)(1.0 / (ctx->mesh_cls_cell > 0 ? ctx->mesh_cls_cell : 1.0));
     return mv;
 }
 
@@ -501,22 +712,53 @@ static int launch_mesh_query(wtp_ctx* ctx, const TP* d_xyz, int64_t n, double of
 
 template <typename TP>
 int launch_mesh_constrain(wtp_ctx* ctx, const Pt<TP>* old, Pt<TP>* cur, int64_t n, int64_t n_fixed, double offset,
-                          const uint8_t* is_bnd, uint8_t* escaped, int32_t* tri_idx, int32_t* n_escaped) {
+                          const uint8_t* is_bnd, uint8_t* escaped, int32_t* tri_idx, int32_t* hint, int32_t* n_escaped) {
     if (ctx->mesh_dtype == WTP_F32)
         hipLaunchKernelGGL((mesh_constrain_kernel<float, TP>), dim3(mesh_grid(n)), dim3(kMeshThreads), 0, ctx->stream, old,
                            cur, n, (int32_t)n_fixed, make_view<float>(ctx), (float)offset, is_bnd, escaped, tri_idx,
-                           n_escaped);
+                           hint, n_escaped);
     else
         hipLaunchKernelGGL((mesh_constrain_kernel<double, TP>), dim3(mesh_grid(n)), dim3(kMeshThreads), 0, ctx->stream,
                            old, cur, n, (int32_t)n_fixed, make_view<double>(ctx), (double)offset, is_bnd, escaped,
-                           tri_idx, n_escaped);
+                           tri_idx, hint, n_escaped);
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;
 }
 template int launch_mesh_constrain<float>(wtp_ctx*, const Pt<float>*, Pt<float>*, int64_t, int64_t, double,
-                                          const uint8_t*, uint8_t*, int32_t*, int32_t*);
+                                          const uint8_t*, uint8_t*, int32_t*, int32_t*, int32_t*);
 template int launch_mesh_constrain<double>(wtp_ctx*, const Pt<double>*, Pt<double>*, int64_t, int64_t, double,
-                                           const uint8_t*, uint8_t*, int32_t*, int32_t*);
+                                           const uint8_t*, uint8_t*, int32_t*, int32_t*, int32_t*);
+
+// Class grid with cells of about `cell` (never more than 2^26 cells); kept when the one already built
+// is at least as fine and not more than twice finer.
+template <typename TM> static int mesh_classes_t(wtp_ctx* ctx, double cell) {
+    double ext[3], vol = 1;
+    for (int a = 0; a < 3; ++a) {
+        ext[a] = ctx->mesh_bbox[3 + a] - ctx->mesh_bbox[a];
+        vol *= ext[a];
+    }
+    const double floor_cell = std::cbrt(vol / 67108864.0);
+    if (!(cell > floor_cell)) cell = floor_cell;
+    if (ctx->mesh_cls_ready && ctx->mesh_cls_cell <= cell * 1.0001 && ctx->mesh_cls_cell >= cell * 0.5) return WTP_OK;
+    int64_t ncell = 1;
+    for (int a = 0; a < 3; ++a) {
+        int64_t d = (int64_t)std::ceil(ext[a] / cell);
+        d = d < 1 ? 1 : d;
+        ctx->mesh_cls_dim[a] = (int)d;
+        ncell *= d;
+    }
+    if (ncell > 200000000LL) return fail(ctx, WTP_ERR_ARG, "mesh class grid too large");
+    int rc;
+    ctx->mesh_cls_ready = false;
+    if ((rc = ensure(ctx, ctx->mesh_cls, (size_t)ncell))) return rc;
+    ctx->mesh_cls_cell = cell;
+    MeshView<TM> mv = make_view<TM>(ctx);
+    hipLaunchKernelGGL((mesh_classify_kernel<TM>), dim3(mesh_grid(ncell)), dim3(kMeshThreads), 0, ctx->stream, mv,
+                       (TM)cell, ncell, (uint8_t*)ctx->mesh_cls.p);
+    WTP_HIP(ctx, hipGetLastError());
+    ctx->mesh_cls_ready = true;
+    return WTP_OK;
+}
 
 static size_t al256(size_t b) { return (b + 255) / 256 * 256; }
 
@@ -560,6 +802,7 @@ WTP_API int wtp_mesh_set(wtp_ctx* ctx, const void* vertices, int64_t nv, const i
         return fail(ctx, WTP_ERR_STATE, "the relax session uses the current mesh: call wtp_relax_end first");
     WTP_HIP(ctx, hipSetDevice(ctx->device));
     ctx->mesh_nt = 0;
+    ctx->mesh_cls_ready = false;
     const int rc = dtype == WTP_F32 ? mesh_set_t<float>(ctx, (const float*)vertices, nv, triangles, nt)
                                     : mesh_set_t<double>(ctx, (const double*)vertices, nv, triangles, nt);
     if (rc) return rc;
@@ -573,6 +816,7 @@ WTP_API int wtp_mesh_clear(wtp_ctx* ctx) {
     if (ctx->relax.active && ctx->relax.wall_active)
         return fail(ctx, WTP_ERR_STATE, "the relax session uses the current mesh: call wtp_relax_end first");
     ctx->mesh_nt = 0;
+    ctx->mesh_cls_ready = false;
     ctx->mesh_face_host.clear();
     return WTP_OK;
 }
@@ -660,6 +904,12 @@ WTP_API int wtp_relax_set_wall(wtp_ctx* ctx, int64_t n_boundary, double offset_d
     const size_t o_cnt = al256(2 * (size_t)nm);
     if ((rc = ensure(ctx, ctx->wall_flags, o_cnt + 256))) return rc;
     if ((rc = ensure(ctx, ctx->wall_tri, 4 * (size_t)nm))) return rc;
+    if ((rc = ensure(ctx, ctx->wall_hint, 4 * (size_t)nm))) return rc;
+    // cells of about one spacing: only the points within a spacing or two of the wall take the exact test
+    const double cell = r.spacing_kind == WTP_SPACING_CONSTANT ? r.spacing_const
+                        : (r.spacing_kind == WTP_SPACING_BOUNDARY_LAYER ? r.sp_p0 : r.spacing_max / 2);
+    if ((rc = ctx->mesh_dtype == WTP_F32 ? mesh_classes_t<float>(ctx, cell) : mesh_classes_t<double>(ctx, cell))) return rc;
+    WTP_HIP(ctx, hipMemsetAsync(ctx->wall_hint.p, 0xff, 4 * (size_t)nm, ctx->stream));
     WTP_HIP(ctx, hipMemsetAsync(ctx->wall_flags.p, 0, o_cnt + 256, ctx->stream));
     if (n_boundary > 0) WTP_HIP(ctx, hipMemsetAsync(ctx->wall_flags.p, 1, (size_t)n_boundary, ctx->stream));
     WTP_HIP(ctx, hipMemsetAsync(ctx->wall_tri.p, 0xff, 4 * (size_t)nm, ctx->stream));
