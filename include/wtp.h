@@ -247,6 +247,11 @@ int wtp_relax_set_wall(wtp_ctx* ctx, int64_t n_boundary, double offset_dist);
  * deposition pass consumes it, src/repel.jl:486-487).  Outputs may be NULL.  */
 int wtp_relax_get_wall(wtp_ctx* ctx, int32_t* tri_out, uint8_t* is_bnd_out, uint8_t* escaped_out,
                        int clear_escaped);
+/* The k nearest snapshot points of arbitrary positions (nq x dim host array of the session's
+ * dtype), searched in the structure of the last rebuild — the `tree` the sweep used: replaces
+ * knn(tree, site, kq, true) of _deposit_escaped! (src/repel.jl:502).  idx_out: nq x k snapshot
+ * indices (0-based), ascending (d2, index); dist_out: nq x k distances or NULL.  */
+int wtp_relax_query_knn(wtp_ctx* ctx, const void* xyz, int64_t nq, int k, int32_t* idx_out, void* dist_out);
 /* Writes membership and landing triangles back after the host-side deposition pass
  * (_deposit_escaped!, src/repel.jl:471-520, serial by design).  */
 int wtp_relax_set_wall_flags(wtp_ctx* ctx, const uint8_t* is_bnd, const int32_t* tri);

@@ -236,3 +236,55 @@ def test_mesh_argument_errors(ctx, wtp):
     finally:
         sess.close()
     ctx.mesh_clear()
+
+
+def test_query_knn_against_the_session_snapshot(ctx, O):
+    """wtp_relax_query_knn: arbitrary positions against the tree of the last rebuild == oracle k-NN of the
+    snapshot with the query appended (the query is then its own nearest hit, dropped here)."""
+    rng = np.random.default_rng(3)
+    snap = rng.random((5000, 3)).astype(np.float32)
+    q = (rng.random((300, 3)) * 1.2 - 0.1).astype(np.float32)
+    sess = ctx.relax(snap, 0, 0.05, dict(kind=2, beta=0.2, u0=1.0), 21, 1e-9, 1e-8)
+    try:
+        with pytest.raises(Exception):
+            sess.query_knn(q, 21)        # no tree yet
+        sess.step(True)
+        idx, dist = sess.query_knn(q, 21, return_dist=True)
+    finally:
+        sess.close()
+    for a in range(0, 300, 7):
+        d2 = ((snap - q[a]) ** 2)
+        d2 = (d2[:, 0] + d2[:, 1]) + d2[:, 2]
+        order = np.lexsort((np.arange(len(snap)), d2))[:21]
+        assert np.array_equal(idx[a], order)
+        assert np.allclose(dist[a], np.sqrt(d2[order]), rtol=1e-6)
+
+
+def test_repel_deposit_ratio_grows_the_boundary(ctx, wtp):
+    """test/repel.jl:326-372: a deliberately sparse boundary; deposition converts escaped volume points
+    (total conserved, boundary grows), a first-iteration cv_target stop leaves everything untouched, and
+    deposition is off by default."""
+    dtype = np.float32
+    v, t, cen, nrm, area, (lo, hi, rng) = _cloud_in_box(wtp, 0, dtype, 41, stem="box")
+    oc = wtp.TriangleOctree(v, t, ctx=ctx)
+    sel = np.arange(0, len(cen), 200)
+    n_sparse = len(sel)
+    s = 3.0
+    cand = (lo + rng.random((4000, 3)) * (hi - lo)).astype(dtype)
+    vol = cand[oc.isinside(cand)][:600]
+    cloud = wtp.PointCloud(wtp.PointBoundary(cen[sel], nrm[sel], area[sel]), wtp.PointVolume(vol))
+    sp = wtp.ConstantSpacing(s)
+    out = wtp.repel(cloud, sp, oc, max_iters=30, deposit_ratio=0.5, ctx=ctx)
+    assert len(out) == len(cloud)
+    assert len(out.boundary) > n_sparse
+    bn = out.boundary["boundary"].normals
+    assert np.all(np.abs(np.linalg.norm(bn, axis=1) - 1) < 1e-3)
+    # deposited points: on the mesh, area = spacing^2, pairwise no closer than ~deposit_ratio*spacing at deposit time
+    q = oc.query(out.boundary.points(), want=("sd",))
+    assert np.abs(q["sd"]).max() < 1e-3
+    assert np.allclose(out.boundary["boundary"].areas[n_sparse:], s * s)
+    assert oc.isinside(out.volume.points()).all()
+    stopped = wtp.repel(cloud, sp, oc, max_iters=30, deposit_ratio=0.5, cv_target=10.0, ctx=ctx)
+    assert len(stopped.boundary) == n_sparse and np.array_equal(stopped.points(), cloud.points())
+    no_dep = wtp.repel(cloud, sp, oc, max_iters=5, ctx=ctx)
+    assert len(no_dep.boundary) == n_sparse

@@ -78,6 +78,7 @@ SIGNATURES = {
     "wtp_relax_set_wall": (_i, [_vp, _i64, _d]),
     "wtp_relax_get_wall": (_i, [_vp, _vp, _vp, _vp, _i]),
     "wtp_relax_set_wall_flags": (_i, [_vp, _vp, _vp]),
+    "wtp_relax_query_knn": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
     "wtp_isinside_greens": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _vp, _vp]),
     "wtp_isinside_winding": (_i, [_vp, _vp, _i64, _vp, _i64, _i, _vp, _vp]),
     "wtp_set_stream": (_i, [_vp, _vp, _i]),

@@ -452,6 +452,7 @@ WTP_API int wtp_create(const int* device_ordinals, int n_dev, wtp_ctx** out) {
     if (const char* e = getenv("WTP_FULL_SELECT")) ctx->full_select = atoi(e);
     if (const char* e = getenv("WTP_STYP_SIGMA")) ctx->styp_sigma = atof(e);
     if (const char* e = getenv("WTP_TIMING")) ctx->timing = atoi(e) != 0;
+    if (const char* e = getenv("WTP_MESH_PACKET")) ctx->mesh_packet = atoi(e);
     *out = ctx;
     return WTP_OK;
 }
@@ -1113,6 +1114,47 @@ WTP_API int wtp_relax_get_spacing(wtp_ctx* ctx, void* spacing_out) {
     }
     WTP_HIP(ctx, hipMemcpyAsync(spacing_out, ctx->spacing_pp.p, ts * (size_t)r.n, hipMemcpyDeviceToHost, ctx->stream));
     return sync(ctx);
+}
+
+template <typename T>
+static int relax_query_knn_t(wtp_ctx* ctx, const void* xyz, int64_t nq, int k, int32_t* idx_out, void* dist_out) {
+    RelaxState& r = ctx->relax;
+    const size_t o_q = (sizeof(T) * (size_t)nq * r.dim + 255) / 256 * 256;
+    int rc;
+    if ((rc = ensure(ctx, ctx->scratch, o_q + sizeof(Pt<T>) * (size_t)nq))) return rc;
+    if ((rc = ensure(ctx, ctx->idx_out, sizeof(int32_t) * (size_t)nq * k))) return rc;
+    if (dist_out && (rc = ensure(ctx, ctx->dist_out, sizeof(T) * (size_t)nq * k))) return rc;
+    WTP_HIP(ctx, hipMemcpyAsync(ctx->scratch.p, xyz, sizeof(T) * (size_t)nq * r.dim, hipMemcpyHostToDevice, ctx->stream));
+    SearchArgs<T> a{};
+    a.grid = (const Grid<T>*)ctx->grid.p;
+    a.snap = (const Pt<T>*)ctx->pts[r.bufS].p;
+    a.cell_start = (const int32_t*)ctx->cell_start.p;
+    a.n = (int32_t)nq;
+    a.k = k;
+    a.idx_out = (int32_t*)ctx->idx_out.p;
+    a.dist_out = dist_out ? (T*)ctx->dist_out.p : nullptr;
+    int sp = span_begin(ctx, 2);
+    rc = launch_query_knn<T>(ctx, a, (const T*)ctx->scratch.p, r.dim, (Pt<T>*)((char*)ctx->scratch.p + o_q));
+    span_end(ctx, sp);
+    if (rc) return rc;
+    WTP_HIP(ctx, hipMemcpyAsync(idx_out, ctx->idx_out.p, sizeof(int32_t) * (size_t)nq * k, hipMemcpyDeviceToHost, ctx->stream));
+    if (dist_out)
+        WTP_HIP(ctx, hipMemcpyAsync(dist_out, ctx->dist_out.p, sizeof(T) * (size_t)nq * k, hipMemcpyDeviceToHost, ctx->stream));
+    return sync(ctx);
+}
+
+WTP_API int wtp_relax_query_knn(wtp_ctx* ctx, const void* xyz, int64_t nq, int k, int32_t* idx_out, void* dist_out) {
+    if (!ctx) return WTP_ERR_ARG;
+    RelaxState& r = ctx->relax;
+    if (!r.active || !r.have_tree || r.bufS < 0 || r.pending.active)
+        return fail(ctx, WTP_ERR_STATE, "wtp_relax_query_knn needs a session that has swept at least once");
+    if (nq < 0 || nq > 2000000000LL) return fail(ctx, WTP_ERR_ARG, "bad nq");
+    if (k < 1 || k > r.n || k > kGenericKMax) return fail(ctx, WTP_ERR_ARG, "k must be in 1..min(n, 128)");
+    if (nq == 0) return WTP_OK;
+    if (!xyz || !idx_out) return fail(ctx, WTP_ERR_ARG, "NULL array");
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    return r.dtype == WTP_F32 ? relax_query_knn_t<float>(ctx, xyz, nq, k, idx_out, dist_out)
+                              : relax_query_knn_t<double>(ctx, xyz, nq, k, idx_out, dist_out);
 }
 
 WTP_API int wtp_spacing_eval(wtp_ctx* ctx, const wtp_spacing_desc* spacing, const void* xyz, int64_t n, int dim,

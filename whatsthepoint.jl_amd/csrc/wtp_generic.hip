@@ -110,6 +110,37 @@ __global__ __launch_bounds__(kThreads) void generic_kernel(SearchArgs<T> a, cons
     }
 }
 
+static inline int blocks_for(int64_t n, int cap) {
+    int64_t b = (n + kThreads - 1) / kThreads;
+    if (b < 1) b = 1;
+    return (int)(b > cap ? cap : b);
+}
+
+// ---- arbitrary query positions against the current snapshot (wtp_relax_query_knn) -----------------
+template <typename T>
+__global__ void pack_queries_kernel(const T* __restrict__ xyz, int64_t nq, int dim, Pt<T>* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    Pt<T> p;
+    p.x = xyz[i * dim];
+    p.y = xyz[i * dim + 1];
+    p.z = dim == 3 ? xyz[i * dim + 2] : (T)0;
+    p.w = id_to_w((T)0, (int32_t)i); // row of the answer
+    out[i] = p;
+}
+
+// a.n = number of queries, a.query = packed queries, a.snap / grid / cell_start = the snapshot searched
+template <typename T> int launch_query_knn(wtp_ctx* ctx, SearchArgs<T>& a, const T* d_xyz, int dim, Pt<T>* d_packed) {
+    hipLaunchKernelGGL(pack_queries_kernel<T>, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, ctx->stream, d_xyz,
+                       (int64_t)a.n, dim, d_packed);
+    a.query = d_packed;
+    a.include_self = 1; // a query is not a snapshot point: nothing to drop
+    hipLaunchKernelGGL((generic_kernel<T, 0>), dim3(blocks_for(a.n, 4096)), dim3(kThreads), 0, ctx->stream, a,
+                       (const int32_t*)nullptr, (const int32_t*)nullptr, 1, 0);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
 // ---- RadiusTopology: count, then fill rows sorted by (d2, id) ---------------------------------
 template <typename T, bool FILL>
 __global__ __launch_bounds__(kThreads) void radius_kernel(SearchArgs<T> a, T r, int32_t* __restrict__ counts,
@@ -159,11 +190,6 @@ __global__ __launch_bounds__(kThreads) void radius_kernel(SearchArgs<T> a, T r, 
     }
 }
 
-static inline int blocks_for(int64_t n, int cap) {
-    int64_t b = (n + kThreads - 1) / kThreads;
-    if (b < 1) b = 1;
-    return (int)(b > cap ? cap : b);
-}
 
 // Exact path = wave-per-query kernel over the list (or all points), then this serial kernel over
 // whatever the wave kernel could not buffer (fb2 list).  WTP_FORCE_GENERIC=2 runs everything
@@ -241,6 +267,7 @@ int launch_radius_fill(wtp_ctx* ctx, SearchArgs<T>& a, T r, const int64_t* d_off
 
 #define INST(T)                                                                              \
     template int launch_generic_topology<T>(wtp_ctx*, SearchArgs<T>&, bool);                 \
+    template int launch_query_knn<T>(wtp_ctx*, SearchArgs<T>&, const T*, int, Pt<T>*);         \
     template int launch_generic_sweep<T>(wtp_ctx*, SearchArgs<T>&, bool);                    \
     template int launch_radius_count<T>(wtp_ctx*, SearchArgs<T>&, T, int32_t*);              \
     template int launch_radius_fill<T>(wtp_ctx*, SearchArgs<T>&, T, const int64_t*, int32_t*);

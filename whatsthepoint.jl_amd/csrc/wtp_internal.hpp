@@ -218,6 +218,7 @@ struct wtp_ctx {
     bool mesh_cls_ready = false;
     int mesh_cls_dim[3] = {0, 0, 0};
     double mesh_cls_cell = 0;
+    int mesh_packet = 0;                // WTP_MESH_PACKET=1: standalone queries walk the tree as wave packets
     wtp::DevBuf sp_hint;       // variable spacings: nearest tree node of each snapshot point at the last sweep
     wtp::DevBuf kd_nodes;      // variable spacings: kd-tree over the boundary points (heap order)
     int64_t kd_m = 0;          // nodes in it; the key below identifies the boundary it was built from
@@ -287,6 +288,7 @@ template <typename T> int launch_wave_radius_count(wtp_ctx* ctx, SearchArgs<T>& 
 template <typename T>
 int launch_wave_radius_fill(wtp_ctx* ctx, SearchArgs<T>& a, T r, const int64_t* d_offsets, int32_t* d_idx);
 template <typename T> int launch_generic_topology(wtp_ctx* ctx, SearchArgs<T>& a, bool all);
+template <typename T> int launch_query_knn(wtp_ctx* ctx, SearchArgs<T>& a, const T* d_xyz, int dim, Pt<T>* d_packed);
 template <typename T> int launch_generic_sweep(wtp_ctx* ctx, SearchArgs<T>& a, bool all);
 inline int total_partials() { return brick_partials() + kWavePartials + kGenericPartials; }
 template <typename T>

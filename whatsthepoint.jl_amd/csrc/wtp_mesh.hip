@@ -340,6 +340,40 @@ __device__ inline uint32_t heap_escape(uint32_t i, uint32_t m) {
     return i;
 }
 
+// A first guess for a query without history: walk down from the root into the child whose box is
+// nearer (ties: left), ~log2(m) steps; the node reached holds a triangle close to the query.
+template <typename T>
+__device__ inline int32_t mesh_greedy_guess(const MeshNode<T>* __restrict__ nodes, int32_t m, const T* q) {
+    uint32_t i = 1;
+    for (;;) {
+        const uint32_t l = 2 * i, rr = 2 * i + 1;
+        if (l > (uint32_t)m) break;
+        if (rr > (uint32_t)m) {
+            i = l;
+            break;
+        }
+        T dl, dr;
+        {
+            const MeshNode<T>& a = nodes[l - 1];
+            const MeshNode<T>& b = nodes[rr - 1];
+            T t[3], u[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const T b1 = a.lo[c] - q[c], a1 = q[c] - a.hi[c];
+                const T m1 = b1 > a1 ? b1 : a1;
+                t[c] = m1 > (T)0 ? m1 : (T)0;
+                const T b2 = b.lo[c] - q[c], a2 = q[c] - b.hi[c];
+                const T m2 = b2 > a2 ? b2 : a2;
+                u[c] = m2 > (T)0 ? m2 : (T)0;
+            }
+            dl = (t[0] * t[0] + t[1] * t[1]) + t[2] * t[2];
+            dr = (u[0] * u[0] + u[1] * u[1]) + u[2] * u[2];
+        }
+        i = dr < dl ? rr : l;
+    }
+    return (int32_t)(i - 1);
+}
+
 // Per-lane walk for a query that brings a good first guess (the tree node of its nearest triangle at the
 // last sweep).  The packet walk below visits the UNION of what 64 lanes want — measured 98 node steps
 // per wave on the box surface although a lane with a tight bound wants ~30 — so with a guess every lane
@@ -361,6 +395,7 @@ __device__ inline Nearest<T> mesh_nearest_guess(const MeshNode<T>* __restrict__ 
         aq = aq > az ? aq : az;
         const T delta = (T)64 * EpsOf<T>::v * (aq > scale ? aq : scale);
         T limit;
+        int32_t guess2 = -1;
         {
             T v[9], cp[3], dv[3];
 #pragma unroll
@@ -372,6 +407,34 @@ __device__ inline Nearest<T> mesh_nearest_guess(const MeshNode<T>* __restrict__ 
             r.tri = nodes[guess].tri_axis & 0x3fffffff;
             r.cp[0] = cp[0], r.cp[1] = cp[1], r.cp[2] = cp[2];
             bn = guess;
+            // a guess farther away than its own triangle is wide is a poor one (the point moved a long
+            // way, e.g. a spacing far coarser than the tessellation): look for a second one from the root
+            T e2 = 0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                T lo = v[a] < v[3 + a] ? v[a] : v[3 + a], hi = v[a] < v[3 + a] ? v[3 + a] : v[a];
+                lo = lo < v[6 + a] ? lo : v[6 + a];
+                hi = hi > v[6 + a] ? hi : v[6 + a];
+                e2 = e2 + (hi - lo) * (hi - lo);
+            }
+            if (r.d2 > e2) {
+                const int32_t g2 = mesh_greedy_guess<T>(nodes, m, q);
+#pragma unroll
+                for (int a = 0; a < 9; ++a) v[a] = nodes[g2].v[a];
+                const int f2 = tri_closest<T>(q, v, v + 3, v + 6, cp);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) dv[a] = q[a] - cp[a];
+                const T d2 = ddot(dv, dv);
+                const int32_t t2 = nodes[g2].tri_axis & 0x3fffffff;
+                if (d2 < r.d2 || (d2 == r.d2 && t2 < r.tri)) {
+                    r.d2 = d2;
+                    r.tri = t2;
+                    r.feat = f2;
+                    r.cp[0] = cp[0], r.cp[1] = cp[1], r.cp[2] = cp[2];
+                    bn = g2;
+                }
+                guess2 = g2;
+            }
             limit = prune_limit<T>(r.d2, delta);
         }
         uint32_t i = 1;
@@ -388,7 +451,7 @@ __device__ inline Nearest<T> mesh_nearest_guess(const MeshNode<T>* __restrict__ 
                 T v[9];
 #pragma unroll
                 for (int a = 0; a < 9; ++a) v[a] = nd.v[a];
-                if ((int32_t)(i - 1) != guess && tri_box_d2<T>(v, q) <= limit) {
+                if ((int32_t)(i - 1) != guess && (int32_t)(i - 1) != guess2 && tri_box_d2<T>(v, q) <= limit) {
                     T cp[3], dv[3];
                     const int f = tri_closest<T>(q, v, v + 3, v + 6, cp);
 #pragma unroll
@@ -590,7 +653,7 @@ template <typename TM, typename TP>
 __global__ void __launch_bounds__(kMeshThreads)
 mesh_query_kernel(const TP* __restrict__ xyz, int64_t n, MeshView<TM> mv, TM offset, TP* __restrict__ sd_out,
                   int32_t* __restrict__ tri_out, TP* __restrict__ cp_out, uint8_t* __restrict__ inside_out,
-                  TP* __restrict__ proj_out) {
+                  TP* __restrict__ proj_out, int packet) {
     __shared__ int32_t stk[kMeshThreads / 64][64];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t span = (n + 63) / 64 * 64;
@@ -598,7 +661,13 @@ mesh_query_kernel(const TP* __restrict__ xyz, int64_t n, MeshView<TM> mv, TM off
         const bool active = i < n;
         const int64_t ii = active ? i : n - 1;
         const TM q[3] = {(TM)xyz[3 * ii], (TM)xyz[3 * ii + 1], (TM)xyz[3 * ii + 2]}; // seam: convert once at entry
-        const Nearest<TM> r = mesh_nearest<TM>(mv.nodes, mv.m, q, active, mv.scale, stk[threadIdx.x >> 6]);
+        Nearest<TM> r;
+        if (packet) {
+            r = mesh_nearest<TM>(mv.nodes, mv.m, q, active, mv.scale, stk[threadIdx.x >> 6]);
+        } else {
+            int32_t bn;
+            r = mesh_nearest_guess<TM>(mv.nodes, mv.m, q, active, mv.scale, mesh_greedy_guess<TM>(mv.nodes, mv.m, q), &bn);
+        }
         if (!active) continue;
         const TM s = side_of<TM>(mv, q, r);
         const TM dist = wsqrt(r.d2);
@@ -622,7 +691,6 @@ __global__ void __launch_bounds__(kMeshThreads)
 mesh_constrain_kernel(const Pt<TP>* __restrict__ old, Pt<TP>* __restrict__ cur, int64_t n, int32_t n_fixed,
                       MeshView<TM> mv, TM offset, const uint8_t* __restrict__ is_bnd, uint8_t* __restrict__ escaped,
                       int32_t* __restrict__ tri_idx, int32_t* __restrict__ hint, int32_t* __restrict__ n_escaped) {
-    __shared__ int32_t stk[kMeshThreads / 64][64];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t span = (n + 63) / 64 * 64;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < span; i += stride) {
@@ -644,16 +712,9 @@ mesh_constrain_kernel(const Pt<TP>* __restrict__ old, Pt<TP>* __restrict__ cur, 
             const int32_t g = search ? hint[id - n_fixed] : -1;
             const bool guessed = search && g >= 0 && g < mv.m;
             int32_t bn = -1;
-            if (__any(guessed)) r = mesh_nearest_guess<TM>(mv.nodes, mv.m, q, guessed, mv.scale, g, &bn);
-            if (__any(search && !guessed)) { // first sweep, or a point that just came near the surface
-                int32_t bn2 = -1;
-                const Nearest<TM> r2 =
-                    mesh_nearest<TM>(mv.nodes, mv.m, q, search && !guessed, mv.scale, stk[threadIdx.x >> 6], -1, &bn2);
-                if (search && !guessed) {
-                    r = r2;
-                    bn = bn2;
-                }
-            }
+            // first sweep, or a point that just came near the surface: a guess found from the root
+            const int32_t g1 = search ? (guessed ? g : mesh_greedy_guess<TM>(mv.nodes, mv.m, q)) : -1;
+            r = mesh_nearest_guess<TM>(mv.nodes, mv.m, q, search, mv.scale, g1, &bn);
             if (search) hint[id - n_fixed] = bn;
         }
         if (!active) continue;
@@ -705,7 +766,7 @@ template <typename TM, typename TP>
 static int launch_mesh_query(wtp_ctx* ctx, const TP* d_xyz, int64_t n, double offset, TP* sd, int32_t* tri, TP* cp,
                              uint8_t* inside, TP* proj) {
     hipLaunchKernelGGL((mesh_query_kernel<TM, TP>), dim3(mesh_grid(n)), dim3(kMeshThreads), 0, ctx->stream, d_xyz, n,
-                       make_view<TM>(ctx), (TM)offset, sd, tri, cp, inside, proj);
+                       make_view<TM>(ctx), (TM)offset, sd, tri, cp, inside, proj, ctx->mesh_packet);
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;
 }

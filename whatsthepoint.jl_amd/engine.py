@@ -353,6 +353,16 @@ class RelaxSession:
                                                           int(bool(clear_escaped))))
         return dict(tri=tri, is_bnd=is_bnd.astype(bool), escaped=esc.astype(bool))
 
+    def query_knn(self, xyz, k: int, return_dist: bool = False):
+        """k nearest snapshot points (of the last rebuild) of arbitrary positions: (nq, k) indices."""
+        q = np.ascontiguousarray(np.atleast_2d(xyz), dtype=self.dtype)
+        if q.shape[1] != self.dim:
+            raise L.WtpArgumentError("queries must have the session's dimension")
+        idx = np.empty((len(q), int(k)), dtype=np.int32)
+        dist = np.empty((len(q), int(k)), dtype=self.dtype) if return_dist else None
+        L.check(self.ctx._h, self._lib.wtp_relax_query_knn(self.ctx._h, _vp(q), len(q), int(k), _vp(idx), _vp(dist)))
+        return (idx, dist) if return_dist else idx
+
     def set_wall_flags(self, is_bnd, tri):
         m = self.n - self.n_fixed
         b = np.ascontiguousarray(is_bnd, dtype=np.uint8)

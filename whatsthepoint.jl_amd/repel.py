@@ -189,8 +189,6 @@ def _repel_octree(cloud, spacing, octree, *, force_model, alpha, alpha_min, k, m
     are re-projected onto the mesh every iteration, escaped volume points bounce back."""
     if deposit_ratio < 0:
         raise WtpArgumentError("deposit_ratio must be ≥ 0")
-    if deposit_ratio > 0:
-        raise NotImplementedError("deposit_ratio > 0 (_deposit_escaped!, src/repel.jl:471-520) is not built yet")
     all_p = cloud.points()
     if all_p.shape[1] != 3:
         raise WtpArgumentError("the octree method is 3-D")
@@ -203,6 +201,10 @@ def _repel_octree(cloud, spacing, octree, *, force_model, alpha, alpha_min, k, m
     diag = (octree.bbox_max - octree.bbox_min).astype(octree.dtype)
     offset = float(octree.dtype.type(1.0e-6) * np.sqrt((diag * diag).sum(dtype=octree.dtype)))  # :143
     wall = dict(octree=octree, n_boundary=n_boundary, offset=offset, deposit=None)
+    if deposit_ratio > 0:
+        kq = min(k, len(all_p))
+        wall["deposit"] = lambda sess, st, it: _deposit_escaped(sess, st, it, octree, spacing, deposit_ratio, offset,
+                                                                kq, ctx)
     p, conv = relax(np.array(all_p, copy=True), np.zeros((0, 3), dtype=all_p.dtype), spacing, force_model,
                     alpha_lo=alpha_min, alpha_max=alpha, k=k, max_iters=max_iters, tol=tol,
                     rebuild_every=rebuild_every, kick_after=kick_after, stall_after=stall_after,
@@ -214,6 +216,44 @@ def _repel_octree(cloud, spacing, octree, *, force_model, alpha, alpha_min, k, m
         wall["is_bnd"] = np.arange(len(p)) < n_boundary
         wall["tri"] = np.full(len(p), -1, dtype=np.int32)
     return _reconstruct_cloud(cloud, p, wall["tri"], wall["is_bnd"], n_boundary, octree, spacing, keep, ctx)
+
+
+def _deposit_escaped(sess, st, it, octree, spacing, deposit_ratio, offset, kq, ctx=None):
+    """_deposit_escaped! (src/repel.jl:471-520): each escaped volume point is projected onto its nearest
+    triangle and becomes a boundary point unless a boundary point already sits within
+    deposit_ratio*spacing of the landing site.  Serial on purpose, like the reference (earlier deposits
+    must be visible to later candidates); the projections and the kq-nearest lists of the landing sites
+    come from the device in one batch each (the lists are searched in the sweep's own snapshot)."""
+    if st["n_escaped"] == 0:
+        return 0
+    w = sess.get_wall(clear_escaped=True)
+    ids = np.nonzero(w["escaped"] & ~w["is_bnd"])[0]   # ascending, like the reference's loop
+    if len(ids) == 0:
+        return 0
+    p = sess.positions()
+    sites, tri = octree.project_to_boundary(p[ids], offset, ctx=ctx)
+    sites = sites.astype(p.dtype, copy=False)
+    sv, const = _spacing_values(spacing, sites)
+    thr = deposit_ratio * (np.full(len(ids), sv, dtype=np.float64) if const else np.asarray(sv, dtype=np.float64))
+    near = sess.query_knn(sites, kq)
+    is_bnd, tri_all = w["is_bnd"].copy(), w["tri"].copy()
+    n_dep = 0
+    for a, i in enumerate(ids):
+        js = near[a].astype(np.int64)
+        js = js[(js != i) & is_bnd[js]]
+        if len(js):
+            d = p[js] - sites[a]
+            if (np.sqrt((d * d).sum(axis=1, dtype=p.dtype)) < thr[a]).any():
+                continue                                  # occupied
+        p[i] = sites[a]
+        is_bnd[i] = True
+        tri_all[i] = tri[a]
+        sess.set_point(int(i), sites[a])
+        n_dep += 1
+    if n_dep:
+        sess.set_wall_flags(is_bnd, tri_all)
+        log.debug("Deposited %d escaped point(s) onto the boundary at iteration %d", n_dep, it)
+    return n_dep
 
 
 def _reconstruct_cloud(cloud, p, tri, is_bnd, n_boundary, octree, spacing, keep, ctx=None):
