@@ -71,6 +71,35 @@ def cpu_baseline(points: int, iters: int):
                 sample=f"{iters} repel iterations on {points} uniform fp32 points (kd-tree + OpenMP oracle, {dt:.1f} s)")
 
 
+def cube_mesh(np, m):
+    """Unit cube, every face m x m quads split into two outward-wound triangles, corners shared."""
+    g = np.arange(m + 1, dtype=np.float64) / m
+    verts, tris, index = [], [], {}
+
+    def vid(p):
+        key = tuple(np.round(p * m).astype(int))
+        if key not in index:
+            index[key] = len(verts)
+            verts.append(p)
+        return index[key]
+
+    for axis in range(3):
+        a1, a2 = (axis + 1) % 3, (axis + 2) % 3
+        for side in (0.0, 1.0):
+            for i in range(m):
+                for j in range(m):
+                    q = []
+                    for di, dj in ((0, 0), (1, 0), (1, 1), (0, 1)):
+                        p = np.zeros(3)
+                        p[axis], p[a1], p[a2] = side, g[i + di], g[j + dj]
+                        q.append(vid(p))
+                    # (e1 x e2) points along +axis for the order 0,1,2: keep it on the far face, flip on the near one
+                    quad = q if side else q[::-1]
+                    tris.append((quad[0], quad[1], quad[2]))
+                    tris.append((quad[0], quad[2], quad[3]))
+    return np.array(verts, dtype=np.float32), np.array(tris, dtype=np.int32)
+
+
 def other_paths(ctx, torch, np, wtp_amd, extra_legs=False):
     """Secondary lines of SURVEY.md §8d, measured in the same run on the same GPU (N=1 only):
     KNNTopology k=21 at 1 M points (C2), RadiusTopology on 1 M points at a radius holding ~21
@@ -131,6 +160,19 @@ def other_paths(ctx, torch, np, wtp_amd, extra_legs=False):
                                        "tera_pairs_per_s": round(len(t) * len(ec) / dev / 1e12, 3),
                                        "inside_fraction": round(float(ins.mean()), 4),
                                        "note": "wtp_isinside_greens, host arrays in and out; VALU-bound (13 instr/pair)"}
+    # isinside(points, octree): signed distance to the nearest of 46 128 triangles, sign from the pseudonormal
+    mv, mt = cube_mesh(np, 62)
+    oc = wtp_amd.TriangleOctree(mv, mt, ctx=ctx)
+    oc.isinside(t[:1000])
+    ctx.timers_reset()
+    t0 = time.perf_counter()
+    ins2 = oc.isinside(t)
+    dt = time.perf_counter() - t0
+    dev = ctx.timers()["other_ms"] * 1e-3
+    out["isinside_octree_2M_x_46k_triangles"] = {
+        "value": round(len(t) / dt / 1e6, 2), "unit": "Mpoints/s", "ms": round(dt * 1e3, 2), "kernel_ms": round(dev * 1e3, 2),
+        "inside_fraction": round(float(ins2.mean()), 4), "agrees_with_greens": round(float((ins2 == ins).mean()), 5),
+        "note": "wtp_mesh_query (bounding-volume tree, per-lane stackless walk), host arrays in and out, unsorted queries"}
     if not extra_legs:
         # The legs below launch the headline's own kernel (brick_kernel<1,0,1>) on other workloads; they are
         # opt-in (--extra-legs) so that a rocprofv3 --stats summary of the default command averages that
@@ -150,6 +192,26 @@ def other_paths(ctx, torch, np, wtp_amd, extra_legs=False):
                                               "final_max_force": float(conv[-1]), "moved": bool(np.abs(pe - xe).max() > 0),
                                               "note": "host array in, 1000 iterations (rebuild every step), host array out"}
     del xe, pe
+    # the octree method (src/repel.jl:122-181): every point moves, wall rule on 46 128 triangles after each sweep
+    cen = mv[mt].mean(axis=1).astype(np.float32)
+    no_ = 10_000_000
+    xo = (wtp_amd.synth.uniform(no_, 3, np.float32, 9) * 0.996 + 0.002).astype(np.float32)
+    so = float(no_) ** (-1.0 / 3.0)
+    oc._resident(ctx)
+    with ctx.relax(np.concatenate([cen, xo]), 0, so, dict(kind=2, beta=0.2, u0=1.0, gamma=3.0), 21, so / 2000, so / 20) as t:
+        t.set_wall(len(cen), 1.0e-6 * 3 ** 0.5)
+        t.run_async_free(3, 1)
+        ctx.timers_reset()
+        t0 = time.perf_counter()
+        _, st = t.run(20, 1)
+        dt = (time.perf_counter() - t0) / 20
+        tm = ctx.timers()
+    out["repel_octree_10M_wall_rule"] = {
+        "value": round((no_ + len(cen)) / dt / 1e6, 1), "unit": "Mpoints/s", "ms_per_iter": round(dt * 1e3, 3),
+        "wall_rule_ms": round((tm["other_ms"]) / 20, 3), "escaped_last_iter": st["n_escaped"],
+        "note": "boundary points re-projected onto the mesh, volume points tested against it, every iteration "
+                "(wall_rule_ms includes the step's reductions, ~0.2 ms)"}
+    del xo
     # graded cloud (BASELINE config 5 / north star "uniform and graded clouds"): thinned uniform stream,
     # h_bulk/h_wall = 4, with its own BoundaryLayerSpacing law evaluated on the device
     ng = 1_000_000

@@ -106,3 +106,43 @@ def test_graded_cloud_generator(wtp):
     d = np.minimum(g, 1 - g).min(1)
     near, far = (d < 0.03).sum() / (1 - 0.94 ** 3), (d > 0.25).sum() / 0.5 ** 3
     assert near > 5 * far                                           # denser at the wall (h ratio 4 -> ~64x)
+
+
+def test_triangle_octree_host_guards(wtp):
+    """TriangleOctree's constructor checks need no device (src/octree/triangle_octree.jl:338-385,
+    427-456; test/octree_isinside.jl:138-165): orientation consistency by exact coordinates, the
+    signed-volume guard against inside-out meshes, pure-triangle input."""
+    import os
+
+    v = np.array([(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1)], dtype=np.float64)
+    t = np.array([(1, 3, 2), (1, 4, 3), (5, 6, 7), (5, 7, 8), (1, 2, 6), (1, 6, 5), (3, 4, 8), (3, 8, 7), (1, 5, 8),
+                  (1, 8, 4), (2, 3, 7), (2, 7, 6)], dtype=np.int32) - 1
+    assert wtp.has_consistent_normals(v, t)
+    assert abs(wtp.signed_volume(v, t) - 1.0) < 1e-12
+    assert abs(wtp.signed_volume(v, t[:, ::-1]) + 1.0) < 1e-12
+    oc = wtp.TriangleOctree(v, t)
+    assert len(oc) == 12 and oc.num_triangles == 12 and oc.dtype == np.float64
+    with pytest.raises(wtp.WtpArgumentError):
+        wtp.TriangleOctree(v, t[:, ::-1].copy())                      # inside-out
+    wtp.TriangleOctree(v, t[:, ::-1].copy(), verify_orientation=False)
+    wtp.TriangleOctree(v, t[:, ::-1].copy(), classify_leaves=False)  # distance-only use: volume not checked
+    flipped = t.copy()
+    flipped[3] = flipped[3, ::-1]
+    assert not wtp.has_consistent_normals(v, flipped)
+    with pytest.raises(wtp.WtpArgumentError):
+        wtp.TriangleOctree(v, flipped)
+    with pytest.raises(wtp.WtpArgumentError):
+        wtp.TriangleOctree(v, np.zeros((4, 4), dtype=np.int32))      # not triangles
+    # triangle soup (every corner duplicated, as a binary STL stores it) is judged by coordinates
+    soup = v[t].reshape(-1, 3)
+    soup_t = np.arange(len(soup), dtype=np.int32).reshape(-1, 3)
+    assert wtp.has_consistent_normals(soup, soup_t)
+    wv, wt = wtp.octree._weld(v[t])
+    assert len(wv) == 8 and np.array_equal(wv[wt], v[t])
+    # the reference's own test surfaces, as committed fixtures
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for stem, vol in (("box", 15625.0), ("cavity", None)):
+        z = np.load(os.path.join(gold, f"{stem}_mesh.npz"))
+        assert wtp.has_consistent_normals(z["vertices"], z["triangles"])
+        sv = wtp.signed_volume(z["vertices"], z["triangles"])
+        assert sv > 0 and (vol is None or abs(sv - vol) < 1e-3 * vol)
