@@ -125,10 +125,13 @@ def other_paths(ctx, torch, np, wtp_amd, extra_legs=False):
     del x, idx
     r = (21.0 / (4.0 / 3.0 * np.pi * n)) ** (1.0 / 3.0)
     ctx.radius(xh[:100000], r)
+    ctx.timers_reset()
     t0 = time.perf_counter()
     off, ridx = ctx.radius(xh, r)
     dt = time.perf_counter() - t0
+    tm = ctx.timers()
     out["radius_topology_1M"] = {"value": round(n / dt / 1e6, 1), "unit": "Mpoints/s", "ms": round(dt * 1e3, 2),
+                                 "kernel_ms": round(tm["hash_ms"] + tm["sweep_ms"] + tm["other_ms"], 3),
                                  "pairs": int(off[-1]), "note": "wtp_radius_count + fill, host arrays in and out "
                                  "(PCIe and the host-side offsets scan included)"}
     # isinside: m = 46 786 elements like the reference's box.stl, synthetic (a cube's faces) so that no file is needed
@@ -242,10 +245,13 @@ def other_paths(ctx, torch, np, wtp_amd, extra_legs=False):
         "exact_path_fraction": round(st["n_fallback"] / ng, 4),
         "note": "64x density contrast; cell edge measured from the occupancy; points whose support exceeds a cell "
                 "take the exact wave-per-query path, which dominates the time (DESIGN.md §4)"}
+    ctx.timers_reset()
     t0 = time.perf_counter()
     off, _ = ctx.radius(xg, 2.5 * hw)
     dt = time.perf_counter() - t0
+    tm = ctx.timers()
     out["graded_radius_topology_1M"] = {"value": round(ng / dt / 1e6, 1), "unit": "Mpoints/s", "ms": round(dt * 1e3, 2),
+                                        "kernel_ms": round(tm["hash_ms"] + tm["sweep_ms"] + tm["other_ms"], 3),
                                         "pairs": int(off[-1]), "note": "r = 2.5 h_wall, host arrays in and out"}
     return out
 

@@ -628,7 +628,6 @@ template <typename T> __device__ inline bool in_bbox(const MeshView<T>& mv, cons
 template <typename T>
 __global__ void __launch_bounds__(kMeshThreads)
 mesh_classify_kernel(MeshView<T> mv, T cell, int64_t ncell, uint8_t* __restrict__ cls) {
-    __shared__ int32_t stk[kMeshThreads / 64][64];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t span = (ncell + 63) / 64 * 64;
     const T half_diag = wsqrt((T)0.75) * cell;
@@ -638,7 +637,9 @@ mesh_classify_kernel(MeshView<T> mv, T cell, int64_t ncell, uint8_t* __restrict_
         const int64_t cx = ii % mv.cdim[0], cy = (ii / mv.cdim[0]) % mv.cdim[1], cz = ii / ((int64_t)mv.cdim[0] * mv.cdim[1]);
         const T q[3] = {mv.lo[0] + ((T)cx + (T)0.5) * cell, mv.lo[1] + ((T)cy + (T)0.5) * cell,
                         mv.lo[2] + ((T)cz + (T)0.5) * cell};
-        const Nearest<T> r = mesh_nearest<T>(mv.nodes, mv.m, q, active, mv.scale, stk[threadIdx.x >> 6]);
+        int32_t bn;
+        const Nearest<T> r =
+            mesh_nearest_guess<T>(mv.nodes, mv.m, q, active, mv.scale, mesh_greedy_guess<T>(mv.nodes, mv.m, q), &bn);
         if (!active) continue;
         const T s = side_of<T>(mv, q, r);
         const T slack = half_diag * (T)1.001 + (T)256 * EpsOf<T>::v * mv.scale;
