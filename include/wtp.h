@@ -256,6 +256,20 @@ int wtp_relax_query_knn(wtp_ctx* ctx, const void* xyz, int64_t nq, int k, int32_
  * (_deposit_escaped!, src/repel.jl:471-520, serial by design).  */
 int wtp_relax_set_wall_flags(wtp_ctx* ctx, const uint8_t* is_bnd, const int32_t* tri);
 
+/* ---- consumers of the k-NN rows ------------------------------------
+ * Replaces compute_normals(points; k) / update_normals! (src/normals.jl:15-69): per point the
+ * eigenvector of the smallest eigenvalue of the covariance of its k nearest points (self
+ * included, KNearestSearch(points, k)), unit length.  eigen() leaves the sign open (the
+ * reference fixes it afterwards with orient_normals!); here the component of largest
+ * magnitude is positive.  normals_out: n x dim of dtype.  2 <= k <= n.  */
+int wtp_pca_normals(wtp_ctx* ctx, const void* xyz, int64_t n, int dim, int dtype, int k, void* normals_out);
+/* Replaces _gradient_limit_field (src/discretization/algorithms/octree.jl:677-717) on the
+ * leaf centres: k-NN graph (self included, distances) + min-plus Jacobi sweeps
+ * h[i] <- min(h[i], min_j h[j] + g d_ij) until the largest relative change of a sweep is
+ * below tol or max_sweeps ran.  h0 / h_out: n values of dtype; sweeps_out: sweeps applied.  */
+int wtp_gradient_limit(wtp_ctx* ctx, const void* centers, int64_t n, int dim, int dtype, int k, const void* h0,
+                       double g, double tol, int max_sweeps, void* h_out, int* sweeps_out);
+
 /* ---- sharded sessions (no counterpart in the reference) --------------
  * One rank sweeps one spatial slab.  Its session's fixed head is the ghost layer received
  * from the neighbouring ranks, its movable tail the points it owns.  The two calls below

@@ -323,3 +323,33 @@ def mesh_query(verts, tris, pts, offset=0.0):
         _p(pts), C.c_int64(n), _p(d2), _p(tri), _p(cp), _p(feat), _p(pn), _p(bbox), ct(offset), _p(sd), _p(inside),
         _p(proj))
     return dict(d2=d2, tri=tri, closest=cp, feature=feat, sd=sd, inside=inside.astype(bool), projected=proj, pn=pn)
+
+
+# ---- consumers of the rows --------------------------------------------------------
+def pca_normals(xyz, k: int = 5):
+    """compute_normals (src/normals.jl:15-46,65-69) with the oracle's own k-NN rows (self included)."""
+    xyz = _xyz(xyz)
+    rows, _ = knn(xyz, k, include_self=True)
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    out = np.empty_like(xyz)
+    getattr(lib(), f"wtpo_pca_normals_{_suf(xyz.dtype)}")(
+        _p(xyz), C.c_int64(len(xyz)), C.c_int(xyz.shape[1]), _p(rows), C.c_int(k), _p(out))
+    return out
+
+
+def gradient_limit(centers, h0, g, k: int = 12, tol: float = 1.0e-3, max_sweeps: int = 2000):
+    """_gradient_limit_field (octree.jl:677-717) on the centres: (limited field, sweeps applied)."""
+    c = _xyz(centers)
+    dt = c.dtype
+    kk = min(k, len(c))
+    rows, dist = knn(c, kk, include_self=True)
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    dist = np.ascontiguousarray(dist, dtype=dt)
+    h0 = np.ascontiguousarray(h0, dtype=dt)
+    out = np.empty_like(h0)
+    ct = C.c_float if dt == np.float32 else C.c_double
+    f = getattr(lib(), f"wtpo_gradient_limit_{_suf(dt)}")
+    f.restype = C.c_int
+    sweeps = f(_p(rows), _p(dist), C.c_int64(len(c)), C.c_int(kk), _p(h0), ct(g), C.c_double(tol), C.c_int(max_sweeps),
+               _p(out))
+    return out, int(sweeps)

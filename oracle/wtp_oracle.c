@@ -13,6 +13,7 @@
  *   src/isinside.jl:17-33,86-106   the isinside post-filter of repel (src/repel.jl:90)
  *   src/octree/geometric_utils.jl:68-136, src/octree/triangle_octree.jl:71-99,221-277,532-607,
  *   src/repel.jl:448-469,522-537   nearest triangle / signed distance / wall rule of the octree method
+ *   src/normals.jl:65-69 (PCA normal), src/discretization/algorithms/octree.jl:677-717 (gradient limiter)
  * Third-party arithmetic it stands in for (source NOT in the reference tree, versions only
  * compat-bounded in Project.toml:39-45): NearestNeighbors.jl 0.4.8+ (KDTree, knn, knn!,
  * inrange), Meshes.jl 0.56/0.57 (KNearestSearch, BallSearch), Distances.jl 0.10

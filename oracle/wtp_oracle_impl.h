@@ -933,6 +933,109 @@ void FN(wtpo_mesh_classify)(const REAL* pts, int64_t n, const REAL* d2, const in
     }
 }
 
+
+/* ======================================================================================
+ * Consumers of the k-NN rows.
+ *   _compute_normal    src/normals.jl:65-69: eigen(Symmetric(cov(v))) -> Q[:, 1], the eigenvector of the
+ *                      smallest eigenvalue of the covariance of the k nearest points (self included).
+ *                      LAPACK's eigen() is not in the reference tree; restated with a cyclic Jacobi
+ *                      iteration (any symmetric eigen solver gives the same vector up to sign and
+ *                      rounding).  Sign: unpinned in the reference (orient_normals! fixes it later);
+ *                      canonical here: the component of largest magnitude is positive.
+ *   _gradient_limit_field   src/discretization/algorithms/octree.jl:677-717
+ * ====================================================================================== */
+static void FN(jacobi_rot)(REAL* app, REAL* aqq, REAL* apq, REAL* arp, REAL* arq, REAL* vp, REAL* vq) {
+    if (*apq == 0) return;
+    const REAL theta = (*aqq - *app) / ((REAL)2 * *apq);
+    const REAL at = theta < 0 ? -theta : theta;
+    REAL t = (REAL)1 / (at + SQRT(theta * theta + (REAL)1));
+    t = theta < 0 ? -t : t;
+    const REAL c = (REAL)1 / SQRT(t * t + (REAL)1), sn = t * c;
+    *app = *app - t * *apq;
+    *aqq = *aqq + t * *apq;
+    *apq = 0;
+    const REAL rp = *arp, rq = *arq;
+    *arp = c * rp - sn * rq;
+    *arq = sn * rp + c * rq;
+    for (int i = 0; i < 3; ++i) {
+        const REAL a = vp[i], b = vq[i];
+        vp[i] = c * a - sn * b;
+        vq[i] = sn * a + c * b;
+    }
+}
+
+void FN(wtpo_pca_normals)(const REAL* xyz, int64_t n, int dim, const int32_t* rows, int k, REAL* out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t* row = rows + i * k;
+        REAL m[3] = {0, 0, 0};
+        for (int j = 0; j < k; ++j)
+            for (int c = 0; c < dim; ++c) m[c] = m[c] + xyz[(int64_t)row[j] * dim + c];
+        const REAL inv = (REAL)1 / (REAL)k;
+        for (int c = 0; c < 3; ++c) m[c] = m[c] * inv;
+        REAL xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
+        for (int j = 0; j < k; ++j) {
+            const REAL* p = xyz + (int64_t)row[j] * dim;
+            const REAL dx = p[0] - m[0], dy = p[1] - m[1], dz = dim == 3 ? p[2] - m[2] : (REAL)0;
+            xx = xx + dx * dx, xy = xy + dx * dy, xz = xz + dx * dz;
+            yy = yy + dy * dy, yz = yz + dy * dz, zz = zz + dz * dz;
+        }
+        REAL vx[3] = {1, 0, 0}, vy[3] = {0, 1, 0}, vz[3] = {0, 0, 1};
+        for (int sweep = 0; sweep < 8; ++sweep) {
+            FN(jacobi_rot)(&xx, &yy, &xy, &xz, &yz, vx, vy);
+            if (dim == 3) {
+                FN(jacobi_rot)(&xx, &zz, &xz, &xy, &yz, vx, vz);
+                FN(jacobi_rot)(&yy, &zz, &yz, &xy, &xz, vy, vz);
+            }
+        }
+        const REAL* v = vx;
+        REAL lam = xx;
+        if (yy < lam) { lam = yy; v = vy; }
+        if (dim == 3 && zz < lam) { lam = zz; v = vz; }
+        int big = 0;
+        REAL ab = v[0] < 0 ? -v[0] : v[0];
+        for (int c = 1; c < dim; ++c) {
+            const REAL a = v[c] < 0 ? -v[c] : v[c];
+            if (a > ab) { ab = a; big = c; }
+        }
+        const REAL sg = v[big] < 0 ? (REAL)-1 : (REAL)1;
+        for (int c = 0; c < dim; ++c) out[i * dim + c] = sg * v[c];
+    }
+}
+
+/* rows / dist: n x k (self included); returns the sweeps applied */
+int FN(wtpo_gradient_limit)(const int32_t* rows, const REAL* dist, int64_t n, int k, const REAL* h0, REAL g, double tol,
+                            int max_sweeps, REAL* out) {
+    REAL* h = (REAL*)malloc(sizeof(REAL) * (size_t)(n > 0 ? n : 1));
+    REAL* hn = (REAL*)malloc(sizeof(REAL) * (size_t)(n > 0 ? n : 1));
+    memcpy(h, h0, sizeof(REAL) * (size_t)n);
+    int sweeps = 0;
+    for (int s = 0; s < max_sweeps; ++s) {
+#pragma omp parallel for schedule(static)
+        for (int64_t a = 0; a < n; ++a) {
+            REAL hi = h[a];
+            for (int t = 0; t < k; ++t) {
+                const REAL cand = h[rows[a * k + t]] + g * dist[a * k + t];
+                if (cand < hi) hi = cand;
+            }
+            hn[a] = hi;
+        }
+        REAL maxrel = 0;
+        for (int64_t a = 0; a < n; ++a) {
+            const REAL d = hn[a] - h[a];
+            const REAL rel = (d < 0 ? -d : d) / h[a];
+            if (rel > maxrel) maxrel = rel;
+        }
+        memcpy(h, hn, sizeof(REAL) * (size_t)n);
+        ++sweeps;
+        if ((double)maxrel < tol) break;
+    }
+    memcpy(out, h, sizeof(REAL) * (size_t)n);
+    free(h);
+    free(hn);
+    return sweeps;
+}
+
 #undef KD_LEAF
 #undef KD_SLACK
 #undef FN

@@ -267,3 +267,70 @@ def test_pseudonormals_of_a_closed_mesh(O):
             n = pn[ti, 1 + s]
             assert np.allclose(n / np.linalg.norm(n), (vert - c) / np.linalg.norm(vert - c), atol=1e-12)
         assert abs(np.linalg.norm(pn[ti, 0]) - 1) < 1e-12
+
+
+# ---- consumers of the rows: PCA normals, gradient limiter ----------------------------------------------
+def _fib_sphere(N=100):
+    ids = np.arange(0.0, N + 0.5 + 1e-9, 1.0)          # 0.0:(N + 0.5) of test/normals.jl:60
+    phi = np.arccos(1 - 2 * ids / N)
+    th = np.pi * (1 + np.sqrt(5)) * ids
+    return np.stack([np.cos(th) * np.sin(phi), np.sin(th) * np.sin(phi), np.cos(phi)], axis=1)
+
+
+def test_pca_normals_known_answers(O):
+    """test/normals.jl:1-24,54-82: the 8-point circle with k = 3 gives the radial directions (either sign),
+    three points of a plane give its normal, the Fibonacci sphere is radial within 10 degrees."""
+    th = np.arange(8) * np.pi / 4
+    circle = np.stack([np.cos(th), np.sin(th)], axis=1)
+    nrm = O.pca_normals(circle, 3)
+    assert np.allclose(np.abs((nrm * circle).sum(axis=1)), 1.0, atol=1e-12)
+    tri = np.array([(1.0, 0, 0), (0, 1.0, 0), (0, 0, 1.0)])
+    n3 = O.pca_normals(tri, 3)
+    assert np.allclose(np.abs(n3 @ (np.ones(3) / np.sqrt(3))), 1.0, atol=1e-12)
+    sph = _fib_sphere()
+    ns = O.pca_normals(sph, 5)
+    ang = np.degrees(np.arccos(np.clip(np.abs((ns * sph).sum(axis=1)), 0, 1)))
+    assert ang.max() < 10.0
+    assert np.allclose(np.linalg.norm(ns, axis=1), 1.0, atol=1e-12)
+
+
+@pytest.mark.parametrize("dtype,dim", [(np.float64, 3), (np.float32, 3), (np.float64, 2)])
+def test_pca_normals_match_lapack(O, dtype, dim):
+    """The Jacobi restatement against numpy.linalg.eigh (LAPACK, what eigen(Symmetric(...)) calls) on the
+    same covariance: the same eigenvector up to sign wherever the two smallest eigenvalues are separated."""
+    rng = np.random.default_rng(8)
+    base = rng.random((3000, dim)).astype(dtype)
+    if dim == 3:
+        base[:, 2] = (0.3 * np.sin(3 * base[:, 0]) + 0.05 * rng.standard_normal(len(base))).astype(dtype)
+    k = 9
+    got = O.pca_normals(base, k)
+    rows, _ = O.knn(base, k, include_self=True)
+    v = base[rows].astype(np.float64)
+    c = v - v.mean(axis=1, keepdims=True)
+    cov = np.einsum("nki,nkj->nij", c, c) / (k - 1)
+    lam, Q = np.linalg.eigh(cov)
+    ref = Q[:, :, 0]
+    gap = (lam[:, 1] - lam[:, 0]) / lam[:, -1]
+    ok = gap > 1e-3
+    dots = np.abs((got.astype(np.float64) * ref).sum(axis=1))
+    assert ok.mean() > 0.9 and dots[ok].min() > (1 - 1e-10 if dtype == np.float64 else 1 - 1e-4)
+    big = np.argmax(np.abs(got), axis=1)
+    assert (got[np.arange(len(got)), big] > 0).all()        # the canonical sign
+
+
+def test_gradient_limit_known_answer(O):
+    """A chain of leaf centres 1 apart, one small source: the envelope grows by g per step until it meets
+    the field (closed form), and the sweep count is the graph distance the front travels + the final check."""
+    n, g = 40, 0.25
+    centers = np.stack([np.arange(n, dtype=np.float64), np.zeros(n), np.zeros(n)], axis=1)
+    h0 = np.full(n, 5.0)
+    h0[7] = 1.0
+    h, sweeps = O.gradient_limit(centers, h0, g, k=3, tol=1e-12, max_sweeps=100)
+    want = np.minimum(5.0, 1.0 + g * np.abs(np.arange(n) - 7))
+    assert np.allclose(h, want, atol=1e-12)
+    assert sweeps == 15 + 1                                  # the front lowers 15 nodes a side (1 + 0.25*16 = 5 changes nothing), + 1 idle sweep
+    h1, s1 = O.gradient_limit(centers, h0, g, k=3, tol=1e-12, max_sweeps=5)
+    assert s1 == 5 and (h1 >= want - 1e-12).all() and not np.allclose(h1, want)
+    # a field that is already g-Lipschitz is a fixpoint after one sweep
+    h2, s2 = O.gradient_limit(centers, want, g, k=3, tol=1e-3, max_sweeps=100)
+    assert s2 == 1 and np.array_equal(h2, want)

@@ -70,6 +70,8 @@ SIGNATURES = {
     "wtp_relax_end": (_i, [_vp]),
     "wtp_relax_get_spacing": (_i, [_vp, _vp]),
     "wtp_spacing_eval": (_i, [_vp, C.POINTER(SpacingDesc), _vp, _i64, _i, _i, _vp]),
+    "wtp_pca_normals": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp]),
+    "wtp_gradient_limit": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _d, _d, _i, _vp, C.POINTER(_i)]),
     "wtp_mesh_set": (_i, [_vp, _vp, _i64, _vp, _i64, _i]),
     "wtp_mesh_clear": (_i, [_vp]),
     "wtp_mesh_face_normals": (_i, [_vp, _vp]),

@@ -531,6 +531,87 @@ WTP_API int wtp_knn(wtp_ctx* ctx, const void* xyz, int64_t n, int dim, int dtype
     return sync(ctx);
 }
 
+// ---- consumers of the rows ------------------------------------------------------
+// rows (self included) and, if wanted, distances of a host cloud, left in ctx->idx_out / dist_out
+static int knn_rows_on_device(wtp_ctx* ctx, const void* xyz, int64_t n, int dim, int dtype, int k, bool want_dist) {
+    const size_t ts = tsize(dtype);
+    int rc;
+    if ((rc = ensure(ctx, ctx->raw_in, ts * (size_t)n * dim))) return rc;
+    if ((rc = ensure(ctx, ctx->idx_out, sizeof(int32_t) * (size_t)n * k))) return rc;
+    if (want_dist && (rc = ensure(ctx, ctx->dist_out, ts * (size_t)n * k))) return rc;
+    WTP_HIP(ctx, hipMemcpyAsync(ctx->raw_in.p, xyz, ts * (size_t)n * dim, hipMemcpyHostToDevice, ctx->stream));
+    void* ddist = want_dist ? ctx->dist_out.p : nullptr;
+    if (dtype == WTP_F32)
+        return knn_dev_t<float>(ctx, (const float*)ctx->raw_in.p, n, dim, k, 1, (int32_t*)ctx->idx_out.p, (float*)ddist);
+    bool done = false;
+    rc = knn_dev_f64(ctx, (const double*)ctx->raw_in.p, n, dim, k, 1, (int32_t*)ctx->idx_out.p, (double*)ddist, &done);
+    if (!rc && !done)
+        rc = knn_dev_t<double>(ctx, (const double*)ctx->raw_in.p, n, dim, k, 1, (int32_t*)ctx->idx_out.p, (double*)ddist);
+    return rc;
+}
+
+WTP_API int wtp_pca_normals(wtp_ctx* ctx, const void* xyz, int64_t n, int dim, int dtype, int k, void* normals_out) {
+    int rc = check_cloud(ctx, xyz, n, dim, dtype);
+    if (rc) return rc;
+    if (k < 2) return fail(ctx, WTP_ERR_ARG, "k must be >= 2 (a covariance needs two points)");
+    if ((rc = check_k(ctx, n, k, 1))) return rc;
+    if ((rc = check_idle(ctx))) return rc;
+    if (!normals_out) return fail(ctx, WTP_ERR_ARG, "normals_out is NULL");
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t ts = tsize(dtype);
+    if ((rc = knn_rows_on_device(ctx, xyz, n, dim, dtype, k, false))) return rc;
+    if ((rc = ensure(ctx, ctx->scratch, ts * (size_t)n * dim))) return rc;
+    int sp = span_begin(ctx, 2);
+    rc = dtype == WTP_F32 ? launch_pca_normals<float>(ctx, (const float*)ctx->raw_in.p, n, dim, (const int32_t*)ctx->idx_out.p,
+                                                      k, (float*)ctx->scratch.p)
+                          : launch_pca_normals<double>(ctx, (const double*)ctx->raw_in.p, n, dim,
+                                                       (const int32_t*)ctx->idx_out.p, k, (double*)ctx->scratch.p);
+    span_end(ctx, sp);
+    if (rc) return rc;
+    WTP_HIP(ctx, hipMemcpyAsync(normals_out, ctx->scratch.p, ts * (size_t)n * dim, hipMemcpyDeviceToHost, ctx->stream));
+    return sync(ctx);
+}
+
+WTP_API int wtp_gradient_limit(wtp_ctx* ctx, const void* centers, int64_t n, int dim, int dtype, int k, const void* h0,
+                               double g, double tol, int max_sweeps, void* h_out, int* sweeps_out) {
+    int rc = check_cloud(ctx, centers, n, dim, dtype);
+    if (rc) return rc;
+    if ((rc = check_k(ctx, n, k, 1))) return rc;
+    if ((rc = check_idle(ctx))) return rc;
+    if (!h0 || !h_out) return fail(ctx, WTP_ERR_ARG, "NULL array");
+    if (max_sweeps < 0) return fail(ctx, WTP_ERR_ARG, "max_sweeps must be >= 0");
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t ts = tsize(dtype);
+    if ((rc = knn_rows_on_device(ctx, centers, n, dim, dtype, k, true))) return rc;
+    const size_t o1 = (ts * (size_t)n + 255) / 256 * 256;
+    if ((rc = ensure(ctx, ctx->scratch, 2 * o1 + 64))) return rc;
+    char* b = (char*)ctx->scratch.p;
+    unsigned long long* st = (unsigned long long*)(b + 2 * o1);
+    WTP_HIP(ctx, hipMemcpyAsync(b, h0, ts * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    WTP_HIP(ctx, hipMemsetAsync(st, 0, 64, ctx->stream));
+    if ((rc = ensure_pinned(ctx, 64))) return rc;
+    unsigned long long* hst = (unsigned long long*)ctx->host_pinned;
+    hst[0] = hst[1] = 0;
+    int sp = span_begin(ctx, 2);
+    for (int first = 0; first < max_sweeps && !hst[0];) { // batches: one read-back per 16 sweeps
+        const int batch = max_sweeps - first < 16 ? max_sweeps - first : 16;
+        rc = dtype == WTP_F32
+                 ? launch_minplus_batch<float>(ctx, (const int32_t*)ctx->idx_out.p, (const float*)ctx->dist_out.p, n, k, g,
+                                               tol, (float*)b, (float*)(b + o1), first, batch, st)
+                 : launch_minplus_batch<double>(ctx, (const int32_t*)ctx->idx_out.p, (const double*)ctx->dist_out.p, n, k,
+                                                g, tol, (double*)b, (double*)(b + o1), first, batch, st);
+        if (rc) return rc;
+        WTP_HIP(ctx, hipMemcpyAsync(hst, st, 16, hipMemcpyDeviceToHost, ctx->stream));
+        if ((rc = sync(ctx))) return rc;
+        first += batch;
+    }
+    span_end(ctx, sp);
+    const int applied = (int)hst[1];
+    if (sweeps_out) *sweeps_out = applied;
+    WTP_HIP(ctx, hipMemcpyAsync(h_out, b + ((applied & 1) ? o1 : 0), ts * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    return sync(ctx);
+}
+
 // ---- RadiusTopology ------------------------------------------------------------------------------
 template <typename T> static int radius_count_t(wtp_ctx* ctx, int64_t n, int dim, double r, int32_t* d_counts) {
     int rc;

@@ -299,6 +299,12 @@ int launch_radius_fill(wtp_ctx* ctx, SearchArgs<T>& a, T r, const int64_t* d_off
 int launch_reduce_partials(wtp_ctx* ctx, const Partial* parts, int n_parts, int used_brick, int used_wave,
                            int used_generic, const int32_t* fb_count, const int32_t* uncovered,
                            const int32_t* escaped, wtp_step_stats* d_stats_slot);
+// consumers of the rows (wtp_consumers.hip)
+template <typename T>
+int launch_pca_normals(wtp_ctx* ctx, const T* d_xyz, int64_t n, int dim, const int32_t* d_rows, int k, T* d_out);
+template <typename T>
+int launch_minplus_batch(wtp_ctx* ctx, const int32_t* d_rows, const T* d_dist, int64_t n, int k, double g, double tol,
+                         T* d_h0, T* d_h1, int first, int sweeps, unsigned long long* d_state);
 // wall rule of the octree method (wtp_mesh.hip)
 template <typename TP>
 int launch_mesh_constrain(wtp_ctx* ctx, const Pt<TP>* old, Pt<TP>* cur, int64_t n, int64_t n_fixed, double offset,

@@ -150,6 +150,28 @@ class Context:
         L.check(self._h, rc)
         return (inside.astype(bool), s) if return_sum else inside.astype(bool)
 
+    # ---- consumers of the rows -------------------------------------------------
+    def pca_normals(self, xyz, k: int = 5):
+        """compute_normals (src/normals.jl:15-46): (n, dim) unit normals, largest component positive."""
+        xyz = _cloud(xyz)
+        out = np.empty_like(xyz)
+        rc = self._lib.wtp_pca_normals(self._h, _vp(xyz), len(xyz), xyz.shape[1], _dtype_code(xyz.dtype), int(k), _vp(out))
+        L.check(self._h, rc)
+        return out
+
+    def gradient_limit(self, centers, h0, g: float, k: int = 12, tol: float = 1.0e-3, max_sweeps: int = 2000):
+        """_gradient_limit_field on leaf centres (octree.jl:677-717): (limited field, sweeps applied)."""
+        c = _cloud(centers)
+        h0 = np.ascontiguousarray(h0, dtype=c.dtype).reshape(-1)
+        if h0.shape != (len(c),):
+            raise L.WtpArgumentError("h0 needs one value per centre")
+        out = np.empty_like(h0)
+        sw = C.c_int(0)
+        rc = self._lib.wtp_gradient_limit(self._h, _vp(c), len(c), c.shape[1], _dtype_code(c.dtype), int(min(k, len(c))),
+                                          _vp(h0), float(g), float(tol), int(max_sweeps), _vp(out), C.byref(sw))
+        L.check(self._h, rc)
+        return out, sw.value
+
     # ---- triangle-mesh geometry index (octree method of repel; src/octree/triangle_octree.jl) -----
     def mesh_set(self, vertices, triangles):
         """vertices (nv, 3) float32/float64 = the index's machine type; triangles (nt, 3) 0-based."""
