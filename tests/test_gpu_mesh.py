@@ -288,3 +288,31 @@ def test_repel_deposit_ratio_grows_the_boundary(ctx, wtp):
     assert len(stopped.boundary) == n_sparse and np.array_equal(stopped.points(), cloud.points())
     no_dep = wtp.repel(cloud, sp, oc, max_iters=5, ctx=ctx)
     assert len(no_dep.boundary) == n_sparse
+
+
+def test_degenerate_triangles_and_exact_ties(ctx, O):
+    """Triangle soups on a coarse lattice: zero-area triangles (their edge parameter is 0/0, the distance NaN,
+    never the minimum — `d2 < best` in the reference, src/octree/triangle_octree.jl:541), repeated corners,
+    and exact distance ties between triangles (canonical: the smaller index).  tools/fuzz_mesh.py found the
+    NaN-guess case this pins."""
+    rng = np.random.default_rng(17)
+    for nt, lattice, mdt, pdt in ((3, 4, np.float32, np.float64), (7, 2, np.float64, np.float32), (400, 2, np.float64, np.float64),
+                                  (3000, 4, np.float32, np.float32)):
+        v = (rng.integers(0, lattice + 1, (3 * nt, 3)).astype(np.float64) / lattice).astype(mdt)
+        t = rng.integers(0, 3 * nt, (nt, 3)).astype(np.int32)
+        q = np.concatenate([rng.integers(-1, lattice + 2, (500, 3)).astype(np.float64) / lattice, rng.random((500, 3)) * 1.4 - 0.2]).astype(pdt)
+        ctx.mesh_set(v, t)
+        got = ctx.mesh_query(q, 1e-6)
+        ref = O.mesh_query(v, t, q, 1e-6)
+        ok = ref["tri"] >= 0
+        assert ok.any() and np.array_equal(got["tri"], ref["tri"])
+        assert np.array_equal(got["closest"][ok], ref["closest"].astype(pdt)[ok])
+        assert np.array_equal(got["sd"][ok], ref["sd"].astype(pdt)[ok]) and np.array_equal(got["inside"], ref["inside"])
+    # nothing but degenerate triangles: no nearest element at all
+    v = np.array([(0, 0, 0), (0, 0, 0), (1, 0, 0)], dtype=np.float64)
+    t1 = np.array([(0, 1, 2)], dtype=np.int32)
+    assert O.mesh_query(v, t1, np.array([(0.5, 0.3, 0.0)]))["tri"][0] == -1
+    ctx.mesh_set(v, t1)
+    got = ctx.mesh_query(np.array([(0.5, 0.3, 0.0)]))
+    assert got["tri"][0] == -1 and not got["inside"][0] and np.isinf(got["sd"][0])
+    ctx.mesh_clear()

@@ -7,6 +7,8 @@ sys.path.insert(0, ROOT)
 import wtp_amd
 z = np.load(os.path.join(ROOT, "tests", "golden", "box_mesh.npz"))
 v, t = z["vertices"], z["triangles"]
+if os.environ.get("WALL_F64"):
+    v = v.astype(np.float64)   # a Float64 index under Float32 points (the reference's usual pairing)
 cen = v[t].mean(axis=1).astype(np.float32)
 ctx = wtp_amd.Context(0)
 oc = wtp_amd.TriangleOctree(v, t, ctx=ctx)

@@ -407,6 +407,13 @@ __device__ inline Nearest<T> mesh_nearest_guess(const MeshNode<T>* __restrict__ 
             r.tri = nodes[guess].tri_axis & 0x3fffffff;
             r.cp[0] = cp[0], r.cp[1] = cp[1], r.cp[2] = cp[2];
             bn = guess;
+            if (!(r.d2 == r.d2)) { // a degenerate triangle (0/0 in its edge parameter): no candidate, like `d2 < best`
+                r.d2 = Lim<T>::inf();
+                r.tri = -1;
+                r.feat = 0;
+                r.cp[0] = q[0], r.cp[1] = q[1], r.cp[2] = q[2];
+                bn = -1;
+            }
             // a guess farther away than its own triangle is wide is a poor one (the point moved a long
             // way, e.g. a spacing far coarser than the tessellation): look for a second one from the root
             T e2 = 0;
@@ -417,7 +424,7 @@ __device__ inline Nearest<T> mesh_nearest_guess(const MeshNode<T>* __restrict__ 
                 hi = hi > v[6 + a] ? hi : v[6 + a];
                 e2 = e2 + (hi - lo) * (hi - lo);
             }
-            if (r.d2 > e2) {
+            if (r.d2 > e2 || r.tri < 0) {
                 const int32_t g2 = mesh_greedy_guess<T>(nodes, m, q);
 #pragma unroll
                 for (int a = 0; a < 9; ++a) v[a] = nodes[g2].v[a];
@@ -507,6 +514,11 @@ __device__ inline Nearest<T> mesh_nearest(const MeshNode<T>* __restrict__ nodes,
         r.tri = hn.tri_axis & 0x3fffffff;
         r.cp[0] = cp[0], r.cp[1] = cp[1], r.cp[2] = cp[2];
         bn = hint;
+        if (!(r.d2 == r.d2)) { // degenerate triangle: no candidate
+            r.d2 = Lim<T>::inf();
+            r.tri = -1;
+            bn = -1;
+        }
         limit = prune_limit<T>(r.d2, delta);
     }
     int sp = 0;
@@ -641,6 +653,10 @@ mesh_classify_kernel(MeshView<T> mv, T cell, int64_t ncell, uint8_t* __restrict_
         const Nearest<T> r =
             mesh_nearest_guess<T>(mv.nodes, mv.m, q, active, mv.scale, mesh_greedy_guess<T>(mv.nodes, mv.m, q), &bn);
         if (!active) continue;
+        if (r.tri < 0) {
+            cls[i] = CLS_BOUNDARY;
+            continue;
+        }
         const T s = side_of<T>(mv, q, r);
         const T slack = half_diag * (T)1.001 + (T)256 * EpsOf<T>::v * mv.scale;
         uint8_t c = CLS_BOUNDARY;
@@ -670,6 +686,16 @@ mesh_query_kernel(const TP* __restrict__ xyz, int64_t n, MeshView<TM> mv, TM off
             r = mesh_nearest_guess<TM>(mv.nodes, mv.m, q, active, mv.scale, mesh_greedy_guess<TM>(mv.nodes, mv.m, q), &bn);
         }
         if (!active) continue;
+        if (r.tri < 0) { // every triangle degenerate: no nearest element (closest_idx == 0 in the reference)
+            if (sd_out) sd_out[i] = Lim<TP>::inf();
+            if (tri_out) tri_out[i] = -1;
+            if (inside_out) inside_out[i] = 0;
+            for (int a = 0; a < 3; ++a) {
+                if (cp_out) cp_out[3 * i + a] = (TP)q[a];
+                if (proj_out) proj_out[3 * i + a] = (TP)q[a];
+            }
+            continue;
+        }
         const TM s = side_of<TM>(mv, q, r);
         const TM dist = wsqrt(r.d2);
         if (sd_out) sd_out[i] = (TP)(s < (TM)0 ? -dist : (s > (TM)0 ? dist : (TM)0));
@@ -719,6 +745,7 @@ mesh_constrain_kernel(const Pt<TP>* __restrict__ old, Pt<TP>* __restrict__ cur, 
             if (search) hint[id - n_fixed] = bn;
         }
         if (!active) continue;
+        if (bnd && r.tri < 0) continue; // no triangle found: the point stays where the sweep put it (src/repel.jl:526)
         if (bnd) {
             const TM* f = mv.pn + 21 * (int64_t)r.tri;
             Pt<TP> o = p;
@@ -729,7 +756,9 @@ mesh_constrain_kernel(const Pt<TP>* __restrict__ old, Pt<TP>* __restrict__ cur, 
             tri_idx[id - n_fixed] = r.tri;
         } else {
             bool inside = false;
-            if (boxed) inside = cls == CLS_INTERIOR || (cls == CLS_BOUNDARY && side_of<TM>(mv, q, r) < (TM)0 && r.d2 > (TM)0);
+            if (boxed)
+                inside = cls == CLS_INTERIOR ||
+                         (cls == CLS_BOUNDARY && r.tri >= 0 && side_of<TM>(mv, q, r) < (TM)0 && r.d2 > (TM)0);
             if (!inside) {
                 const Pt<TP> xo = old[i];
                 Pt<TP> o = p;
