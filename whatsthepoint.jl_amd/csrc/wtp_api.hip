@@ -453,6 +453,7 @@ WTP_API int wtp_create(const int* device_ordinals, int n_dev, wtp_ctx** out) {
     if (const char* e = getenv("WTP_STYP_SIGMA")) ctx->styp_sigma = atof(e);
     if (const char* e = getenv("WTP_TIMING")) ctx->timing = atoi(e) != 0;
     if (const char* e = getenv("WTP_MESH_PACKET")) ctx->mesh_packet = atoi(e);
+    if (const char* e = getenv("WTP_GRID_REUSE")) ctx->grid_reuse_max = atoi(e) >= 0 ? atoi(e) : ctx->grid_reuse_max;
     *out = ctx;
     return WTP_OK;
 }
@@ -917,9 +918,17 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
                 r.brick_hcap = hc < 640 ? 640 : (hc > 2560 ? 2560 : hc);
             }
             r.grid_tuned = true;
+            r.grid_age = 0;
         } else {
+            // The bounding box moves by at most a spacing per sweep: it is recomputed every few rebuilds only
+            // (and always after a point was placed by hand, a fixed head was swapped, or with a clipped box).
+            const bool reuse = r.grid_age < ctx->grid_reuse_max && !r.moved_by_hand && !ctx->hash_view.active &&
+                               !ctx->box_active;
+            ctx->reuse_grid = reuse;
+            r.grid_age = reuse ? r.grid_age + 1 : 0;
             rc = build_hash<T>(ctx, (const Pt<T>*)ctx->pts[r.bufP].p, (Pt<T>*)ctx->pts[t].p, r.n, r.dim, r.k, 0.0, rho_cs,
                                min_cell, r.cell_scale);
+            ctx->reuse_grid = false;
         }
         span_end(ctx, sp);
         ctx->hash_view.active = false;

@@ -322,67 +322,40 @@ __global__ void scatter_kernel(const Pt<T>* __restrict__ pts, int64_t n, const i
 // kCanonMax keep arrival order (results stay exact; only fp summation order may vary).
 static constexpr int kCanonMax = 96;
 
-template <typename T> struct CanonCap;
-template <> struct CanonCap<float> { static constexpr int pts = 3072; };   // 48 KiB of LDS
-template <> struct CanonCap<double> { static constexpr int pts = 1536; };
-
-// A workgroup owns kThreads consecutive cells = one contiguous run of the sorted array.  The run
-// is staged into LDS with coalesced loads, each thread insertion-sorts its own cell by id there and
-// writes it back if anything moved.  Runs too large for LDS sort in place in global memory.
+// One thread per cell.  On rebuilds the input is the previous canonical order and a run of same-cell
+// points keeps its order through the ranking (lanes of one wave are served in lane order), so most cells
+// arrive sorted: the pass reads the ids (one 4-byte load per point) and insertion-sorts in place, in
+// global memory, the cells that are out of order (those that gained a point from another wave).
+// Measured per 10 M-point rebuild: staging every cell through LDS and sorting there 110 us; this 85 us;
+// marking candidate cells in cell_rank_kernel (bitmap / byte map) and visiting only those 91-97 us (a third
+// of the cells exchange a point per iteration, and the marks cost atomics or a second memset); a register
+// rank sort with all loads in flight 125 us.  The pass is bound by touching the lines the scatter just wrote.
 template <typename T>
 __global__ __launch_bounds__(kThreads) void canon_kernel(Pt<T>* __restrict__ pts,
                                                          const int32_t* __restrict__ cell_start,
                                                          const Grid<T>* __restrict__ gp) {
-    __shared__ Pt<T> buf[CanonCap<T>::pts];
     const int ncells = gp->ncells;
-    for (int c0 = blockIdx.x * kThreads; c0 < ncells; c0 += gridDim.x * kThreads) {
-        const int c1 = c0 + kThreads < ncells ? c0 + kThreads : ncells;
-        const int p0 = cell_start[c0], p1 = cell_start[c1];
-        const int cell = c0 + threadIdx.x;
-        int s = 0, m = 0;
-        if (cell < c1) {
-            s = cell_start[cell];
-            m = cell_start[cell + 1] - s;
+    for (int cell = blockIdx.x * kThreads + threadIdx.x; cell < ncells; cell += gridDim.x * kThreads) {
+        const int s = cell_start[cell];
+        const int m = cell_start[cell + 1] - s;
+        if (m < 2 || m > kCanonMax) continue;
+        bool sorted = true;
+        int prev = w_to_id(pts[s].w);
+        for (int i = 1; i < m; ++i) {
+            const int cur = w_to_id(pts[s + i].w);
+            sorted = sorted && prev <= cur;
+            prev = cur;
         }
-        const bool in_lds = (p1 - p0) <= CanonCap<T>::pts;
-        __syncthreads();
-        if (in_lds) {
-            for (int i = p0 + threadIdx.x; i < p1; i += kThreads) buf[i - p0] = pts[i];
-            __syncthreads();
-        }
-        if (m >= 2 && m <= kCanonMax) {
-            if (in_lds) {
-                Pt<T>* b = buf + (s - p0);
-                bool moved = false;
-                for (int i = 1; i < m; ++i) {
-                    const int kid = w_to_id(b[i].w);
-                    if (w_to_id(b[i - 1].w) <= kid) continue; // in place already: one 4-byte compare
-                    const Pt<T> key = b[i];
-                    int j = i - 1;
-                    while (j >= 0 && w_to_id(b[j].w) > kid) {
-                        b[j + 1] = b[j];
-                        --j;
-                    }
-                    b[j + 1] = key;
-                    moved = true;
-                }
-                // On rebuilds the input is the previous canonical order and a run of same-cell points
-                // keeps its order through the ranking, so nearly every cell arrives sorted: only the
-                // cells that really changed are written back (the pass is read-only otherwise).
-                if (moved)
-                    for (int i = 0; i < m; ++i) pts[s + i] = b[i];
-            } else {
-                for (int i = 1; i < m; ++i) {
-                    const Pt<T> key = pts[s + i];
-                    const int kid = w_to_id(key.w);
-                    int j = i - 1;
-                    while (j >= 0 && w_to_id(pts[s + j].w) > kid) {
-                        pts[s + j + 1] = pts[s + j];
-                        --j;
-                    }
-                    pts[s + j + 1] = key;
-                }
+        if (sorted) continue;
+        for (int i = 1; i < m; ++i) {
+            const Pt<T> key = pts[s + i];
+            const int kid = w_to_id(key.w);
+            int j = i - 1;
+            while (j >= 0 && w_to_id(pts[s + j].w) > kid) {
+                pts[s + j + 1] = pts[s + j];
+                --j;
             }
+            pts[s + j + 1] = key;
         }
     }
 }
@@ -666,9 +639,16 @@ int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, in
     if (rho_k < 1.0) rho_k = 1.0;
 
     WTP_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)(cap + 1), st));
-    hipLaunchKernelGGL(bbox_kernel<T>, dim3(nbb), dim3(kThreads), 0, st, in, n_in, part, v_old, v_fixed_old);
-    hipLaunchKernelGGL(grid_setup_kernel<T>, dim3(1), dim3(64), 0, st, part, nbb, g, n, dim, rho_k, radius, min_cell, cap,
-                       cell_scale, ctx->box_active ? (const double*)ctx->box_dev.p : (const double*)nullptr);
+    // ctx->reuse_grid (one-shot, set by the relax session): keep the Grid of the previous build — origin, cell edge,
+    // cell counts — and skip the bounding-box pass.  A point that has left the old box since is clamped into an
+    // edge cell, which the kernels treat as unbounded outward, so the search stays exact.
+    const bool reuse = ctx->reuse_grid;
+    ctx->reuse_grid = false;
+    if (!reuse) {
+        hipLaunchKernelGGL(bbox_kernel<T>, dim3(nbb), dim3(kThreads), 0, st, in, n_in, part, v_old, v_fixed_old);
+        hipLaunchKernelGGL(grid_setup_kernel<T>, dim3(1), dim3(64), 0, st, part, nbb, g, n, dim, rho_k, radius, min_cell,
+                           cap, cell_scale, ctx->box_active ? (const double*)ctx->box_dev.p : (const double*)nullptr);
+    }
     ctx->ncells_dev = &g->ncells;
     const int nb = grid_for(n_in, kThreads, 16384);
     hipLaunchKernelGGL(cell_rank_kernel<T>, dim3(nb), dim3(kThreads), 0, st, in, n_in, g, cnt, cr, v_old, v_fixed_old);

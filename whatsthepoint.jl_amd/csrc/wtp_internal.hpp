@@ -155,6 +155,7 @@ struct RelaxState {
     double spacing_max = 0;  // largest spacing value (host-side max of the per-point array)
     int brick_hcap = 0;      // LDS point capacity of the sweep's brick kernel (0 = not chosen yet)
     bool grid_tuned = false; // cell_scale / spacing_typ measured on the first rebuild
+    int grid_age = 0;             // rebuilds since the grid (bounding box, cell edge) was last computed
     int sweeps_since_rebuild = 0; // every sweep moves a point by at most its spacing (src/repel.jl:286-289)
     bool moved_by_hand = false;   // wtp_relax_set since the last rebuild: that bound is gone
     double cell_scale = 1.0; // < 1: cells shrunk because the occupied ones hold more than the box average
@@ -196,6 +197,8 @@ struct wtp_ctx {
     wtp::DevBuf grid, bbox_part, occ;
     wtp::HashView hash_view;   // consumed by the next build_hash call (set and cleared by the caller)
     wtp::DevBuf box_dev;       // robust box {lo xyz, hi xyz} (doubles) + histogram scratch behind it
+    bool reuse_grid = false;   // one-shot: the next build_hash keeps the previous Grid (no bounding-box pass)
+    int grid_reuse_max = 7;    // WTP_GRID_REUSE: rebuilds of a relax session that may reuse a grid (0 = never)
     bool box_active = false;   // grid_setup clips the bounding box to box_dev (outliers piled into edge cells)
     const void* ncells_dev = nullptr; // device address of Grid::ncells of the last build_hash
     wtp::DevBuf idx_out, dist_out, counts_out;
