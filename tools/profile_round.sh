@@ -17,5 +17,5 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" "SQ_BUSY
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_$N -o $TAG -- python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu --no-other-paths > /dev/null 2>> $OUT/log.txt || echo "pmc pass $C failed" | tee -a $OUT/log.txt
 done
 find $OUT -name "*_kernel_stats.csv" | head -3 | tee -a $OUT/log.txt
-python3 $REPO/tools/pmc_summary.py $(find $OUT -name "*counter_collection.csv") > $OUT/pmc_summary.txt 2>> $OUT/log.txt
+python3 $REPO/tools/rocpd_summary.py pmc $(find $OUT -path "*pmc_*" -name "*_results.db") > $OUT/pmc_summary.txt 2>> $OUT/log.txt
 tail -1 $OUT/bench_under_rocprof.json | cut -c1-300
