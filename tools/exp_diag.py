@@ -27,3 +27,4 @@ lib.wtp_debug_diag(ctx._h, out)
 names = ["stage", "query_setup", "scan", "select", "prune_compact", "step_out", "force_loop"]
 tot = sum(out[i] for i in range(7)) or 1
 print({names[i]: round(out[i] / tot, 4) for i in range(7)}, "waves", out[7], "cycles/wave", tot // max(out[7], 1))
+print("raw", [int(out[i]) for i in range(8)], "scan lane utilisation (WTP_DIAG=2 builds)", round(out[4] / max(out[3], 1), 3))

@@ -516,6 +516,10 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
                             pressure = true;
                             break;
                         }
+#if WTP_DIAG == 2 // lane utilisation of the scan: slots 3 / 4 count wave steps x 64 and busy lane steps
+                        dt[3] += 64;
+                        dt[4] += (unsigned long long)__popcll(__ballot(pa < ea));
+#endif
                         f4 c[SU];
                         lds_read_group(c, lds_base + pa);
 #pragma unroll
