@@ -435,7 +435,7 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
             // ---- scan / select loop: one instance of the network serves prunes and the final cut
             // LDS byte addresses: points at [0, hcap*16), this lane's ring row j at ring_b + j*512
             const uint32_t ring_b = (uint32_t)hcap * 16u + (uint32_t)kPadBytes + (uint32_t)tid * 2u;
-            const uint32_t dump_b = ring_b + (uint32_t)nb * (kBrickThreads * 2u);
+            // (row nb of the ring is a spare row: an unconditional append of a rejected candidate may land there)
             const uint32_t full_b = ring_b + (uint32_t)(nb - SU) * (kBrickThreads * 2u);
             uint32_t ra = ring_b; // next free ring entry
             const uint32_t lds_base = (uint32_t)(uintptr_t)smem_raw; // LDS byte address of the point area
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
                             const float tl = (pa + 16u * u < ea) ? (CS ? tau_s : tau) : -1.f;
                             bool take = d <= tl;
                             if (MODE == 0) take = take && (w_to_id(c[u].w) != skip_id);
-                            *reinterpret_cast<uint16_t*>(smem_raw + (take ? ra : dump_b)) = (uint16_t)(pa + 16u * u);
+                            *reinterpret_cast<uint16_t*>(smem_raw + ra) = (uint16_t)(pa + 16u * u); // unconditional: a slot past the end is rewritten or never read
                             ra += take ? (kBrickThreads * 2u) : 0u;
                         }
                         pa += 16u * SU;
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
                             const float d = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
                             const float tl = (pa + 16u * u < ea) ? tau_s : -1.f;
                             const bool take = d <= tl;
-                            *reinterpret_cast<uint16_t*>(smem_raw + (take ? ra : dump_b)) = (uint16_t)(pa + 16u * u);
+                            *reinterpret_cast<uint16_t*>(smem_raw + ra) = (uint16_t)(pa + 16u * u); // unconditional: a slot past the end is rewritten or never read
                             ra += take ? (kBrickThreads * 2u) : 0u;
                         }
                         pa += 16u * SU;
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
                             const float tl = (pa + 16u * u < ea) ? (CS ? tau_s : tau) : -1.f;
                             bool take = d <= tl;
                             if (MODE == 0) take = take && (w_to_id(c[u].w) != skip_id);
-                            *reinterpret_cast<uint16_t*>(smem_raw + (take ? ra : dump_b)) = (uint16_t)(pa + 16u * u);
+                            *reinterpret_cast<uint16_t*>(smem_raw + ra) = (uint16_t)(pa + 16u * u); // unconditional: a slot past the end is rewritten or never read
                             ra += take ? (kBrickThreads * 2u) : 0u;
                         }
                         pa += 16u * SU;
