@@ -631,6 +631,10 @@ template <typename T> static int radius_count_t(wtp_ctx* ctx, int64_t n, int dim
     a.query = sorted;
     a.cell_start = (const int32_t*)ctx->cell_start.p;
     a.n = (int32_t)n;
+    if ((rc = ensure(ctx, ctx->fb_list, sizeof(int32_t) * (size_t)n))) return rc;
+    if ((rc = ensure(ctx, ctx->fb_count, 64))) return rc;
+    a.fb_list = (int32_t*)ctx->fb_list.p; // queries the brick kernel hands back to the wave kernel
+    a.fb_count = (int32_t*)ctx->fb_count.p;
     sp = span_begin(ctx, 1);
     rc = launch_radius_count<T>(ctx, a, (T)r, d_counts);
     span_end(ctx, sp);
@@ -646,6 +650,8 @@ template <typename T> static int radius_fill_t(wtp_ctx* ctx, const int64_t* d_of
     a.n = (int32_t)ctx->rad_n;
     a.fb2_list = (int32_t*)ctx->fb2_list.p;
     a.fb2_count = (int32_t*)ctx->fb2_count.p;
+    a.fb_list = (int32_t*)ctx->fb_list.p; // ensured by the count phase
+    a.fb_count = (int32_t*)ctx->fb_count.p;
     int sp = span_begin(ctx, 1);
     int rc = launch_radius_fill<T>(ctx, a, (T)ctx->rad_r, d_off, d_idx);
     span_end(ctx, sp);

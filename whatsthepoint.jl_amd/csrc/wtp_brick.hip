@@ -248,7 +248,7 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
 
     const Grid<float> g = *a.grid;
     const int K = KT > 0 ? KT : a.k;
-    const bool skip_self = (MODE == 0) && !a.include_self;
+    const bool skip_self = (MODE == 0 && !a.include_self) || MODE == 2; // radius rows never hold the point itself (src/topology.jl:96)
     const float cap2 = (a.gamma_cap * g.c) * (a.gamma_cap * g.c);
     Acc acc = acc_empty();
     unsigned long long dt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -393,6 +393,13 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
             const int hx = cx - ox, hy = cy - oy, hz = cz - oz;
             const float g2 = safe_radius2(g, qp.x, qp.y, qp.z, cx, cy, cz, 1);
             float tau = g2 < cap2 ? g2 : cap2;
+            // MODE 2 (RadiusTopology): the threshold IS the answer — everything with d2 <= r^2 (inclusive,
+            // src/topology.jl:93); the 27 cells are complete when r lies inside the provable radius
+            bool rad_fail = false;
+            if (MODE == 2) {
+                rad_fail = !(a.radius2 <= g2);
+                tau = rad_fail ? -1.f : a.radius2;
+            }
             const int32_t skip_id = skip_self ? qid : -1; // ids are >= 0
             int cnt = 0;
             bool giveup = false;
@@ -533,7 +540,7 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
                             }
                             const float tl = (pa + 16u * u < ea) ? (CS ? tau_s : tau) : -1.f;
                             bool take = d <= tl;
-                            if (MODE == 0) take = take && (w_to_id(c[u].w) != skip_id);
+                            if (MODE != 1) take = take && (w_to_id(c[u].w) != skip_id);
                             *reinterpret_cast<uint16_t*>(smem_raw + ra) = (uint16_t)(pa + 16u * u); // unconditional: a slot past the end is rewritten or never read
                             ra += take ? (kBrickThreads * 2u) : 0u;
                         }
@@ -599,7 +606,7 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
                             // and-ing lane masks on the scalar unit: no VALU->SALU->VALU round trip
                             const float tl = (pa + 16u * u < ea) ? (CS ? tau_s : tau) : -1.f;
                             bool take = d <= tl;
-                            if (MODE == 0) take = take && (w_to_id(c[u].w) != skip_id);
+                            if (MODE != 1) take = take && (w_to_id(c[u].w) != skip_id);
                             *reinterpret_cast<uint16_t*>(smem_raw + ra) = (uint16_t)(pa + 16u * u); // unconditional: a slot past the end is rewritten or never read
                             ra += take ? (kBrickThreads * 2u) : 0u;
                         }
@@ -615,7 +622,7 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
                     }
                 }
                 cnt = (int)((ra - ring_b) / (kBrickThreads * 2u));
-                if (CS) { // no selection: everything within tau is in the ring
+                if (CS || MODE == 2) { // no selection: everything within tau is in the ring
                     if (pressure) { // some lane's ring is full (dense cluster): only that lane gives up
                         if (ra > full_b) {
                             giveup = true;
@@ -660,7 +667,27 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
             }
 
             bool fallback = !WTP_ABL && ((!CS && cnt < K) || giveup || cs_fail || (kth == next)); // tie at the cut -> exact path
-            if (MODE == 0) {
+            if (MODE == 2) fallback = giveup || rad_fail || cnt > 32; // longer rows: the wave kernel's LDS list
+            if (MODE == 2) {
+                if (!fallback) {
+                    if (!a.rad_fill) {
+                        a.rad_counts[qid] = cnt; // first phase of the CSR: row lengths
+                    } else {
+                        uint64_t k[32];
+#pragma unroll
+                        for (int j = 0; j < 32; ++j) {
+                            const float4 c = lds_pt(pts, ring[(j < cnt ? j : 0) * kBrickThreads]);
+                            const uint32_t d = f2u(dist2<float>(qp.x, qp.y, qp.z, c.x, c.y, c.z));
+                            k[j] = j < cnt ? (((uint64_t)d << 32) | (uint32_t)w_to_id(c.w)) : ~0ull;
+                        }
+                        WTP_SORTNET_32(k)
+                        int32_t* orow = a.idx_out + a.rad_offsets[qid];
+#pragma unroll
+                        for (int j = 0; j < 32; ++j)
+                            if (j < cnt) orow[j] = (int32_t)(uint32_t)k[j];
+                    }
+                }
+            } else if (MODE == 0) {
                 if (!fallback) {
                     // survivors: exactly K entries with d2 <= cut; canonical order by 64-bit key
                     ring_compact(pts, ring, cnt, u2f(kth), qp.x, qp.y, qp.z);
@@ -797,6 +824,15 @@ template <int MODE, int KT, int CS> static int brick_launch(wtp_ctx* ctx, Search
 }
 
 int brick_partials() { return 256 * 4 + 8; }
+
+// RadiusTopology through the brick kernel (fp32): rows of up to 32 entries are counted / sorted and written
+// here, the rest (longer rows, queries the 27 cells cannot certify, bricks too large for LDS) is appended
+// to a.fb_list for the wave kernel.  The caller cleared a.fb_count.
+int launch_brick_radius(wtp_ctx* ctx, SearchArgs<float>& a) {
+    a.gamma_cap = (float)ctx->gamma_cap;
+    a.k = 1;
+    return brick_launch<2, 0, 0>(ctx, a);
+}
 
 template <> int launch_topology<float>(wtp_ctx* ctx, SearchArgs<float>& a) {
     if (a.k > kFastKMax - 1 || ctx->force_generic) return launch_generic_topology<float>(ctx, a, true);

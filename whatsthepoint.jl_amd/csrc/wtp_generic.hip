@@ -233,6 +233,14 @@ template <typename T> int launch_generic_sweep(wtp_ctx* ctx, SearchArgs<T>& a, b
     return WTP_OK;
 }
 
+// The brick kernel serves fp32 clouds (WTP_FORCE_GENERIC switches it off); the caller provides the hand-back list.
+template <typename T> static bool brick_radius_usable(wtp_ctx*, SearchArgs<T>&) { return false; }
+template <> bool brick_radius_usable<float>(wtp_ctx* ctx, SearchArgs<float>& a) {
+    return !ctx->force_generic && a.fb_list != nullptr && a.fb_count != nullptr;
+}
+template <typename T> static int brick_radius(wtp_ctx*, SearchArgs<T>&) { return WTP_OK; }
+template <> int brick_radius<float>(wtp_ctx* ctx, SearchArgs<float>& a) { return launch_brick_radius(ctx, a); }
+
 template <typename T>
 int launch_radius_count(wtp_ctx* ctx, SearchArgs<T>& a, T r, int32_t* d_counts) {
     if (ctx->force_generic == 2) {
@@ -242,7 +250,17 @@ int launch_radius_count(wtp_ctx* ctx, SearchArgs<T>& a, T r, int32_t* d_counts) 
         WTP_HIP(ctx, hipGetLastError());
         return WTP_OK;
     }
-    return launch_wave_radius_count<T>(ctx, a, r, d_counts);
+    if (brick_radius_usable<T>(ctx, a)) { // fp32: LDS-staged brick kernel first, the wave kernel takes what it hands back
+        WTP_HIP(ctx, hipMemsetAsync(a.fb_count, 0, sizeof(int32_t), ctx->stream));
+        a.radius2 = r * r;
+        a.rad_counts = d_counts;
+        a.rad_offsets = nullptr;
+        a.rad_fill = 0;
+        int rc = brick_radius<T>(ctx, a);
+        if (rc) return rc;
+        return launch_wave_radius_count<T>(ctx, a, r, d_counts, a.fb_list, a.fb_count);
+    }
+    return launch_wave_radius_count<T>(ctx, a, r, d_counts, nullptr, nullptr);
 }
 
 // Rows are ranked by the wave kernel; rows longer than its LDS list (fb2 list) are insertion-
@@ -257,7 +275,19 @@ int launch_radius_fill(wtp_ctx* ctx, SearchArgs<T>& a, T r, const int64_t* d_off
         return WTP_OK;
     }
     WTP_HIP(ctx, hipMemsetAsync(a.fb2_count, 0, sizeof(int32_t), ctx->stream));
-    int rc = launch_wave_radius_fill<T>(ctx, a, r, d_offsets, d_idx);
+    int rc;
+    if (brick_radius_usable<T>(ctx, a)) {
+        WTP_HIP(ctx, hipMemsetAsync(a.fb_count, 0, sizeof(int32_t), ctx->stream));
+        a.radius2 = r * r;
+        a.rad_counts = nullptr;
+        a.rad_offsets = d_offsets;
+        a.rad_fill = 1;
+        a.idx_out = d_idx;
+        if ((rc = brick_radius<T>(ctx, a))) return rc;
+        rc = launch_wave_radius_fill<T>(ctx, a, r, d_offsets, d_idx, a.fb_list, a.fb_count);
+    } else {
+        rc = launch_wave_radius_fill<T>(ctx, a, r, d_offsets, d_idx, nullptr, nullptr);
+    }
     if (rc) return rc;
     hipLaunchKernelGGL((radius_kernel<T, true>), dim3(256), dim3(kThreads), 0, ctx->stream, a, r, (int32_t*)nullptr,
                        d_offsets, d_idx, (T*)ctx->scratch.p, (const int32_t*)a.fb2_list, (const int32_t*)a.fb2_count);

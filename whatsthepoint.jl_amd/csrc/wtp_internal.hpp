@@ -106,6 +106,11 @@ template <typename T> struct SearchArgs {
     // blocks each sweep kernel was launched with = partial slots it wrote (set by the launchers):
     // brick [0, used_brick), wave [brick_partials(), +used_wave), serial [n_partials - kGenericPartials, +used_generic)
     int32_t used_brick, used_wave, used_generic;
+    // RadiusTopology through the brick kernel: r^2, row lengths out (count phase) or row starts in (fill phase)
+    T radius2;
+    int32_t* rad_counts;
+    const int64_t* rad_offsets;
+    int32_t rad_fill;
     // fallback work list
     int32_t* fb_list;
     int32_t* fb_count;
@@ -287,13 +292,17 @@ template <typename T> int launch_brick_cs(wtp_ctx* ctx, SearchArgs<T>& a);
 // exact paths: wave-per-query (list = fb_list or all points), then the serial kernel on fb2_list
 template <typename T> int launch_wave_topology(wtp_ctx* ctx, SearchArgs<T>& a, bool all);
 template <typename T> int launch_wave_sweep(wtp_ctx* ctx, SearchArgs<T>& a, bool all);
-template <typename T> int launch_wave_radius_count(wtp_ctx* ctx, SearchArgs<T>& a, T r, int32_t* d_counts);
 template <typename T>
-int launch_wave_radius_fill(wtp_ctx* ctx, SearchArgs<T>& a, T r, const int64_t* d_offsets, int32_t* d_idx);
+int launch_wave_radius_count(wtp_ctx* ctx, SearchArgs<T>& a, T r, int32_t* d_counts, const int32_t* list,
+                             const int32_t* list_count);
+template <typename T>
+int launch_wave_radius_fill(wtp_ctx* ctx, SearchArgs<T>& a, T r, const int64_t* d_offsets, int32_t* d_idx,
+                            const int32_t* list, const int32_t* list_count);
 template <typename T> int launch_generic_topology(wtp_ctx* ctx, SearchArgs<T>& a, bool all);
 template <typename T> int launch_query_knn(wtp_ctx* ctx, SearchArgs<T>& a, const T* d_xyz, int dim, Pt<T>* d_packed);
 template <typename T> int launch_generic_sweep(wtp_ctx* ctx, SearchArgs<T>& a, bool all);
 inline int total_partials() { return brick_partials() + kWavePartials + kGenericPartials; }
+int launch_brick_radius(wtp_ctx* ctx, SearchArgs<float>& a);
 template <typename T>
 int launch_radius_count(wtp_ctx* ctx, SearchArgs<T>& a, T r, int32_t* d_counts);
 template <typename T>

@@ -368,7 +368,9 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
 template <typename T, bool FILL>
 __global__ __launch_bounds__(kThreads) void wave_radius_kernel(SearchArgs<T> a, T r, int32_t* __restrict__ counts,
                                                                const int64_t* __restrict__ offsets,
-                                                               int32_t* __restrict__ idx_out) {
+                                                               int32_t* __restrict__ idx_out,
+                                                               const int32_t* __restrict__ list,
+                                                               const int32_t* __restrict__ list_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -377,7 +379,9 @@ __global__ __launch_bounds__(kThreads) void wave_radius_kernel(SearchArgs<T> a, 
     const T r2 = r * r; // inclusive, compared as d2 <= r*r
     const int wave_global = blockIdx.x * kWaves + wave;
     const int wave_stride = gridDim.x * kWaves;
-    for (int slot = wave_global; slot < a.n; slot += wave_stride) {
+    const int nq = list ? *list_count : a.n; // list: the queries the brick kernel handed back
+    for (int qi = wave_global; qi < nq; qi += wave_stride) {
+        const int slot = list ? list[qi] : qi;
         const Pt<T> q = a.snap[slot];
         const int32_t id = w_to_id(q.w);
         const int cx = cell_coord(g, q.x, 0), cy = cell_coord(g, q.y, 1), cz = cell_coord(g, q.z, 2);
@@ -438,27 +442,30 @@ __global__ __launch_bounds__(kThreads) void wave_radius_kernel(SearchArgs<T> a, 
 
 template <typename T> static size_t wave_smem() { return sizeof(WaveSmem<T>) * kWaves + sizeof(Acc) * kWaves; }
 
-template <typename T> int launch_wave_radius_count(wtp_ctx* ctx, SearchArgs<T>& a, T r, int32_t* d_counts) {
-    int64_t want = ((int64_t)a.n + kWaves - 1) / kWaves;
-    int nb = (int)(want > 16384 ? 16384 : (want < 1 ? 1 : want));
+template <typename T>
+int launch_wave_radius_count(wtp_ctx* ctx, SearchArgs<T>& a, T r, int32_t* d_counts, const int32_t* list,
+                             const int32_t* list_count) {
+    int64_t want = ((int64_t)a.n / (list ? 16 : 1) + kWaves - 1) / kWaves;
+    int nb = (int)(want > 16384 ? 16384 : (want < 64 ? 64 : want));
     hipLaunchKernelGGL((wave_radius_kernel<T, false>), dim3(nb), dim3(kThreads), 0, ctx->stream, a, r,
-                       d_counts, (const int64_t*)nullptr, (int32_t*)nullptr);
+                       d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, list, list_count);
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;
 }
 
 template <typename T>
-int launch_wave_radius_fill(wtp_ctx* ctx, SearchArgs<T>& a, T r, const int64_t* d_offsets, int32_t* d_idx) {
+int launch_wave_radius_fill(wtp_ctx* ctx, SearchArgs<T>& a, T r, const int64_t* d_offsets, int32_t* d_idx,
+                            const int32_t* list, const int32_t* list_count) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)wave_radius_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)wave_smem<T>());
         attr_set = true;
     }
-    int64_t want = ((int64_t)a.n + kWaves - 1) / kWaves;
-    int nb = (int)(want > 16384 ? 16384 : (want < 1 ? 1 : want));
+    int64_t want = ((int64_t)a.n / (list ? 16 : 1) + kWaves - 1) / kWaves;
+    int nb = (int)(want > 16384 ? 16384 : (want < 64 ? 64 : want));
     hipLaunchKernelGGL((wave_radius_kernel<T, true>), dim3(nb), dim3(kThreads), wave_smem<T>(), ctx->stream, a, r,
-                       (int32_t*)nullptr, d_offsets, d_idx);
+                       (int32_t*)nullptr, d_offsets, d_idx, list, list_count);
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;
 }
@@ -493,8 +500,8 @@ template <typename T> int launch_wave_sweep(wtp_ctx* ctx, SearchArgs<T>& a, bool
 
 #define INST(T)                                                                                  \
     template int launch_wave_topology<T>(wtp_ctx*, SearchArgs<T>&, bool);                        \
-    template int launch_wave_radius_count<T>(wtp_ctx*, SearchArgs<T>&, T, int32_t*);             \
-    template int launch_wave_radius_fill<T>(wtp_ctx*, SearchArgs<T>&, T, const int64_t*, int32_t*); \
+    template int launch_wave_radius_count<T>(wtp_ctx*, SearchArgs<T>&, T, int32_t*, const int32_t*, const int32_t*); \
+    template int launch_wave_radius_fill<T>(wtp_ctx*, SearchArgs<T>&, T, const int64_t*, int32_t*, const int32_t*, const int32_t*); \
     template int launch_wave_sweep<T>(wtp_ctx*, SearchArgs<T>&, bool);
 INST(float)
 INST(double)
