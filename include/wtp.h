@@ -137,6 +137,11 @@ int wtp_knn_dev(wtp_ctx* ctx, const void* d_xyz, int64_t n, int dim, int dtype, 
 int wtp_radius_count(wtp_ctx* ctx, const void* xyz, int64_t n, int dim, int dtype,
                      double r, int32_t* counts_out);
 int wtp_radius_fill(wtp_ctx* ctx, const int64_t* offsets, int32_t* idx_out);
+/* The same first phase with the exclusive scan done on the device: offsets_out[n+1] (int64) is what the
+ * caller needs to allocate idx_out (offsets_out[n] entries); the offsets also stay resident, so the fill
+ * that follows may pass offsets = NULL.  Saves the counts' trip to the host and the offsets' trip back.  */
+int wtp_radius_offsets(wtp_ctx* ctx, const void* xyz, int64_t n, int dim, int dtype, double r,
+                       int64_t* offsets_out);
 
 /* ---- repel: _relax! ------------------------------------------------------------------ */
 

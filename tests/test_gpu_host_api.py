@@ -128,3 +128,18 @@ def test_repel_cull_ratio(O, wtp, ctx):
     culled = wtp.repel(cloud, wtp.ConstantSpacing(0.08), cull_ratio=0.6, **kw).volume.points()
     want = O.cull_mask(everyone, np.full(len(everyone), 0.08, np.float32), 0.6)   # src/repel.jl:91-93
     assert np.array_equal(culled, everyone[want]) and 20 < (~want).sum() < 1500
+
+
+def test_radius_offsets_on_device_equals_two_phase(ctx, O, wtp):
+    """wtp_radius_offsets (scan on the device, fill with resident offsets) == the caller-side scan of
+    wtp_radius_count / wtp_radius_fill == the oracle, incl. empty rows, rows past the brick kernel's 32
+    entries and clouds smaller than one scan tile."""
+    rng = np.random.default_rng(12)
+    for n, dim, dtype, r in ((50000, 3, np.float32, 0.06), (1500, 2, np.float64, 0.05), (70000, 3, np.float32, 0.02),
+                             (5, 3, np.float32, 0.5), (9000, 3, np.float32, 0.2)):
+        x = rng.random((n, dim)).astype(dtype)
+        off, idx = ctx.radius(x, r)
+        off2, idx2 = ctx.radius_two_phase(x, r)
+        ooff, oidx = O.radius(x, r)
+        assert np.array_equal(off, off2) and np.array_equal(idx, idx2)
+        assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)

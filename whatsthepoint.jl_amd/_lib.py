@@ -57,6 +57,7 @@ SIGNATURES = {
     "wtp_knn_dev": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp]),
     "wtp_radius_count": (_i, [_vp, _vp, _i64, _i, _i, _d, _vp]),
     "wtp_radius_fill": (_i, [_vp, _vp, _vp]),
+    "wtp_radius_offsets": (_i, [_vp, _vp, _i64, _i, _i, _d, _vp]),
     "wtp_relax_init": (_i, [_vp, _vp, _i64, _i64, _i, _i, C.POINTER(SpacingDesc), C.POINTER(ForceDesc), _i, _d, _d]),
     "wtp_relax_init_dev": (_i, [_vp, _vp, _i64, _i64, _i, _i, C.POINTER(SpacingDesc), C.POINTER(ForceDesc), _i, _d, _d]),
     "wtp_relax_step": (_i, [_vp, _i, C.POINTER(StepStats)]),

@@ -667,6 +667,7 @@ WTP_API int wtp_radius_count(wtp_ctx* ctx, const void* xyz, int64_t n, int dim, 
     WTP_HIP(ctx, hipSetDevice(ctx->device));
     const size_t ts = tsize(dtype);
     ctx->rad_valid = false;
+    ctx->rad_offsets_dev = false;
     ctx->relax.have_tree = false;
     if ((rc = ensure(ctx, ctx->raw_in, ts * (size_t)n * dim))) return rc;
     if ((rc = ensure(ctx, ctx->counts_out, sizeof(int32_t) * (size_t)n))) return rc;
@@ -685,15 +686,58 @@ WTP_API int wtp_radius_count(wtp_ctx* ctx, const void* xyz, int64_t n, int dim, 
     return WTP_OK;
 }
 
+// count + exclusive scan on the device: the caller gets the offsets it needs to allocate, the counts never
+// cross the bus and the offsets stay resident for the fill
+WTP_API int wtp_radius_offsets(wtp_ctx* ctx, const void* xyz, int64_t n, int dim, int dtype, double r,
+                               int64_t* offsets_out) {
+    int rc = check_cloud(ctx, xyz, n, dim, dtype);
+    if (rc) return rc;
+    if (!(r >= 0) || !std::isfinite(r)) return fail(ctx, WTP_ERR_ARG, "radius must be finite and >= 0");
+    if (!offsets_out) return fail(ctx, WTP_ERR_ARG, "offsets_out is NULL");
+    if ((rc = check_idle(ctx))) return rc;
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t ts = tsize(dtype);
+    ctx->rad_valid = false;
+    ctx->rad_offsets_dev = false;
+    ctx->relax.have_tree = false;
+    if ((rc = ensure(ctx, ctx->raw_in, ts * (size_t)n * dim))) return rc;
+    if ((rc = ensure(ctx, ctx->counts_out, sizeof(int32_t) * (size_t)n))) return rc;
+    if ((rc = ensure(ctx, ctx->dist_out, sizeof(int64_t) * (size_t)(n + 1)))) return rc; // offsets live here until the fill
+    WTP_HIP(ctx, hipMemcpyAsync(ctx->raw_in.p, xyz, ts * (size_t)n * dim, hipMemcpyHostToDevice, ctx->stream));
+    rc = dtype == WTP_F32 ? radius_count_t<float>(ctx, n, dim, r, (int32_t*)ctx->counts_out.p)
+                          : radius_count_t<double>(ctx, n, dim, r, (int32_t*)ctx->counts_out.p);
+    if (rc) return rc;
+    // (radius_count_t uses scratch for nothing; the scan's tile sums go there)
+    if ((rc = ensure(ctx, ctx->scratch, offsets_scan_tmp_bytes(n)))) return rc;
+    int sp = span_begin(ctx, 2);
+    rc = launch_offsets_scan(ctx, (const int32_t*)ctx->counts_out.p, n, (int64_t*)ctx->scratch.p, (int64_t*)ctx->dist_out.p);
+    span_end(ctx, sp);
+    if (rc) return rc;
+    WTP_HIP(ctx, hipMemcpyAsync(offsets_out, ctx->dist_out.p, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    if ((rc = sync(ctx))) return rc;
+    ctx->rad_n = n;
+    ctx->rad_dim = dim;
+    ctx->rad_dtype = dtype;
+    ctx->rad_r = r;
+    ctx->rad_valid = true;
+    ctx->rad_offsets_dev = true;
+    ctx->rad_nnz = offsets_out[n];
+    return WTP_OK;
+}
+
 WTP_API int wtp_radius_fill(wtp_ctx* ctx, const int64_t* offsets, int32_t* idx_out) {
     if (!ctx) return WTP_ERR_ARG;
     if (!ctx->rad_valid) return fail(ctx, WTP_ERR_STATE, "wtp_radius_fill needs a preceding wtp_radius_count");
-    if (!offsets) return fail(ctx, WTP_ERR_ARG, "offsets is NULL");
+    if (!offsets && !ctx->rad_offsets_dev)
+        return fail(ctx, WTP_ERR_ARG, "offsets is NULL (only wtp_radius_offsets leaves them on the device)");
     const int64_t n = ctx->rad_n;
-    if (offsets[0] != 0) return fail(ctx, WTP_ERR_ARG, "offsets[0] must be 0");
-    for (int64_t i = 0; i < n; ++i)
-        if (offsets[i + 1] < offsets[i]) return fail(ctx, WTP_ERR_ARG, "offsets must be non-decreasing");
-    const int64_t nnz = offsets[n];
+    if (offsets) {
+        if (offsets[0] != 0) return fail(ctx, WTP_ERR_ARG, "offsets[0] must be 0");
+        for (int64_t i = 0; i < n; ++i)
+            if (offsets[i + 1] < offsets[i]) return fail(ctx, WTP_ERR_ARG, "offsets must be non-decreasing");
+    }
+    const int64_t nnz = offsets ? offsets[n] : ctx->rad_nnz;
     if (nnz > 0 && !idx_out) return fail(ctx, WTP_ERR_ARG, "idx_out is NULL");
     WTP_HIP(ctx, hipSetDevice(ctx->device));
     const size_t ts = tsize(ctx->rad_dtype);
@@ -703,8 +747,9 @@ WTP_API int wtp_radius_fill(wtp_ctx* ctx, const int64_t* offsets, int32_t* idx_o
     if ((rc = ensure(ctx, ctx->dist_out, sizeof(int64_t) * (size_t)(n + 1)))) return rc; // offsets staging
     if ((rc = ensure(ctx, ctx->fb2_list, sizeof(int32_t) * (size_t)n))) return rc;
     if ((rc = ensure(ctx, ctx->fb2_count, 64))) return rc;
-    WTP_HIP(ctx, hipMemcpyAsync(ctx->dist_out.p, offsets, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyHostToDevice,
-                                ctx->stream));
+    if (offsets)
+        WTP_HIP(ctx, hipMemcpyAsync(ctx->dist_out.p, offsets, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyHostToDevice,
+                                    ctx->stream));
     rc = ctx->rad_dtype == WTP_F32 ? radius_fill_t<float>(ctx, (const int64_t*)ctx->dist_out.p, (int32_t*)ctx->idx_out.p)
                                    : radius_fill_t<double>(ctx, (const int64_t*)ctx->dist_out.p, (int32_t*)ctx->idx_out.p);
     if (rc) return rc;

@@ -709,6 +709,79 @@ __global__ void set_point_kernel(Pt<T>* __restrict__ pts, int64_t n, int32_t id,
     }
 }
 
+// ---- exclusive scan of row lengths -> CSR offsets (int32 counts, int64 offsets; wtp_radius_offsets) ------
+static constexpr int kOffTile = 2048; // elements per block
+__global__ __launch_bounds__(kThreads) void offsets_tile_sum_kernel(const int32_t* __restrict__ cnt, int64_t n,
+                                                                   int64_t* __restrict__ tile_sum) {
+    __shared__ int64_t sm[kThreads / 64];
+    const int64_t base = (int64_t)blockIdx.x * kOffTile;
+    int64_t s = 0;
+    for (int i = threadIdx.x; i < kOffTile; i += kThreads)
+        if (base + i < n) s += cnt[base + i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t t = 0;
+        for (int w = 0; w < kThreads / 64; ++w) t += sm[w];
+        tile_sum[blockIdx.x] = t;
+    }
+}
+__global__ void offsets_tile_scan_kernel(int64_t* __restrict__ tile_sum, int64_t ntiles) { // one thread: ntiles <= n / 2048
+    int64_t run = 0;
+    for (int64_t i = 0; i < ntiles; ++i) {
+        const int64_t t = tile_sum[i];
+        tile_sum[i] = run;
+        run += t;
+    }
+    tile_sum[ntiles] = run;
+}
+__global__ __launch_bounds__(kThreads) void offsets_apply_kernel(const int32_t* __restrict__ cnt, int64_t n,
+                                                                const int64_t* __restrict__ tile_sum,
+                                                                int64_t* __restrict__ off) {
+    // a tile = kThreads runs of kOffTile / kThreads consecutive elements, one run per thread
+    constexpr int kRun = kOffTile / kThreads;
+    __shared__ int64_t sm[kThreads];
+    const int64_t base = (int64_t)blockIdx.x * kOffTile + (int64_t)threadIdx.x * kRun;
+    int32_t v[kRun];
+    int64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < kRun; ++i) {
+        v[i] = base + i < n ? cnt[base + i] : 0;
+        s += v[i];
+    }
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t run = tile_sum[blockIdx.x];
+        for (int t = 0; t < kThreads; ++t) {
+            const int64_t x = sm[t];
+            sm[t] = run;
+            run += x;
+        }
+    }
+    __syncthreads();
+    int64_t run = sm[threadIdx.x];
+#pragma unroll
+    for (int i = 0; i < kRun; ++i) {
+        if (base + i < n) off[base + i] = run;
+        run += v[i];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) off[n] = tile_sum[gridDim.x];
+}
+
+// d_off[0..n] = exclusive scan of d_cnt[0..n); d_tmp: (ntiles + 1) int64
+int launch_offsets_scan(wtp_ctx* ctx, const int32_t* d_cnt, int64_t n, int64_t* d_tmp, int64_t* d_off) {
+    const int64_t ntiles = (n + kOffTile - 1) / kOffTile;
+    hipLaunchKernelGGL(offsets_tile_sum_kernel, dim3((unsigned)ntiles), dim3(kThreads), 0, ctx->stream, d_cnt, n, d_tmp);
+    hipLaunchKernelGGL(offsets_tile_scan_kernel, dim3(1), dim3(1), 0, ctx->stream, d_tmp, ntiles);
+    hipLaunchKernelGGL(offsets_apply_kernel, dim3((unsigned)ntiles), dim3(kThreads), 0, ctx->stream, d_cnt, n,
+                       (const int64_t*)d_tmp, d_off);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+size_t offsets_scan_tmp_bytes(int64_t n) { return sizeof(int64_t) * (size_t)((n + kOffTile - 1) / kOffTile + 2); }
+
 template <typename T>
 int launch_unpermute(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int64_t n_fixed, int dim, T* d_out) {
     hipLaunchKernelGGL(unpermute_kernel<T>, dim3(grid_for(n, kThreads, 8192)), dim3(kThreads), 0,

@@ -238,7 +238,9 @@ struct wtp_ctx {
     int64_t rad_n = 0;
     int rad_dim = 0, rad_dtype = 0;
     double rad_r = 0;
+    int64_t rad_nnz = 0;
     bool rad_valid = false;
+    bool rad_offsets_dev = false; // wtp_radius_offsets left the CSR offsets in dist_out (device): fill may take them from there
     wtp::RelaxState relax;
     // timers
     bool timing = true;
@@ -278,6 +280,8 @@ int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, in
 // occupancy of the grid the last build_hash made: d_out3 = [sum cnt^2, sum cnt, max cnt]
 int launch_occupancy(wtp_ctx* ctx, unsigned long long* d_out3);
 template <typename T> int launch_sum(wtp_ctx* ctx, const T* d_v, int64_t n, double* d_out);
+int launch_offsets_scan(wtp_ctx* ctx, const int32_t* d_cnt, int64_t n, int64_t* d_tmp, int64_t* d_off);
+size_t offsets_scan_tmp_bytes(int64_t n);
 // per-axis coordinate histograms over d_range = {lo xyz, hi xyz}: 3 x 1024 bins
 template <typename T>
 int launch_axis_hist(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int dim, const double* d_range, unsigned int* d_hist);

@@ -90,6 +90,19 @@ class Context:
         """CSR stencils: (offsets int64[n+1], idx int32[nnz]); rows ascending (d2, index)."""
         xyz = _cloud(xyz)
         n, dim = xyz.shape
+        # row lengths are scanned on the device; the offsets come back once and stay resident for the fill
+        offsets = np.empty(n + 1, dtype=np.int64)
+        rc = self._lib.wtp_radius_offsets(self._h, _vp(xyz), n, dim, _dtype_code(xyz.dtype), float(r), _vp(offsets))
+        L.check(self._h, rc)
+        idx = np.empty(max(int(offsets[-1]), 1), dtype=np.int32)
+        rc = self._lib.wtp_radius_fill(self._h, None, _vp(idx))
+        L.check(self._h, rc)
+        return offsets, idx[: int(offsets[-1])]
+
+    def radius_two_phase(self, xyz, r: float):
+        """The caller-side scan of the C ABI's first form (wtp_radius_count -> offsets -> wtp_radius_fill)."""
+        xyz = _cloud(xyz)
+        n, dim = xyz.shape
         counts = np.empty(n, dtype=np.int32)
         rc = self._lib.wtp_radius_count(self._h, _vp(xyz), n, dim, _dtype_code(xyz.dtype), float(r), _vp(counts))
         L.check(self._h, rc)
