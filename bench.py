@@ -132,8 +132,8 @@ def other_paths(ctx, torch, np, wtp_amd, extra_legs=False):
     tm = ctx.timers()
     out["radius_topology_1M"] = {"value": round(n / dt / 1e6, 1), "unit": "Mpoints/s", "ms": round(dt * 1e3, 2),
                                  "kernel_ms": round(tm["hash_ms"] + tm["sweep_ms"] + tm["other_ms"], 3),
-                                 "pairs": int(off[-1]), "note": "wtp_radius_count + fill, host arrays in and out "
-                                 "(PCIe and the host-side offsets scan included)"}
+                                 "pairs": int(off[-1]), "note": "wtp_radius_offsets + wtp_radius_fill (brick_kernel<2,0,0>, scan on the device), host arrays "
+                                 "in and out: value/ms include PCIe (82 MB of rows), kernel_ms is the device time"}
     # isinside: m = 46 786 elements like the reference's box.stl, synthetic (a cube's faces) so that no file is needed
     m_side = 88
     g = (np.arange(m_side, dtype=np.float32) + 0.5) / m_side
