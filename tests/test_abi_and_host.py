@@ -146,3 +146,19 @@ def test_triangle_octree_host_guards(wtp):
         assert wtp.has_consistent_normals(z["vertices"], z["triangles"])
         sv = wtp.signed_volume(z["vertices"], z["triangles"])
         assert sv > 0 and (vol is None or abs(sv - vol) < 1e-3 * vol)
+
+
+def test_combine_surfaces(wtp):
+    """combine_surfaces! (src/surface_operations.jl:7-31; test/surface_operations.jl:1-67): merged in the
+    boundary's order under the first given name; unknown names are an assertion error."""
+    rng = np.random.default_rng(0)
+    a, b, c = (rng.random((n, 3)) for n in (4, 6, 3))
+    bnd = wtp.PointBoundary(surfaces={"surface1": wtp.PointSurface(a, a * 0 + 1, np.ones(4)),
+                                      "surface2": wtp.PointSurface(b, b * 0 + 2, np.ones(6)),
+                                      "surface3": wtp.PointSurface(c, c * 0 + 3, np.ones(3))})
+    wtp.combine_surfaces(bnd, "surface3", "surface1")
+    assert list(bnd.surfaces) == ["surface2", "surface3"] and len(bnd) == 13
+    s = bnd["surface3"]
+    assert np.array_equal(s.points(), np.concatenate([a, c])) and np.array_equal(s.normals[:, 0], [1] * 4 + [3] * 3)
+    with pytest.raises(AssertionError):
+        wtp.combine_surfaces(bnd, "surface2", "nonexistent")

@@ -16,7 +16,7 @@ from .repel import repel, relax
 from .metrics import metrics, spacing_metrics, spacing_fidelity_metrics
 from .inside import isinside
 from .octree import TriangleOctree, has_consistent_normals, signed_volume
-from .normals import compute_normals, update_normals, orient_normals, split_surface
+from .normals import compute_normals, update_normals, orient_normals, split_surface, combine_surfaces
 from .limiter import gradient_limit_field
 from . import synth, stl, octree
 

@@ -117,6 +117,22 @@ def _angle(u, v):
     return np.arctan2(np.linalg.norm(np.cross(u, v), axis=1), (u * v).sum(axis=1))
 
 
+def combine_surfaces(cloud, *surfs):
+    """combine_surfaces!(boundary, surfs...) (src/surface_operations.jl:7-31): the named surfaces are merged,
+    in the boundary's own order, into one surface that takes the first given name."""
+    bnd = cloud.boundary if isinstance(cloud, PointCloud) else cloud
+    for name in surfs:
+        assert name in bnd.surfaces, "Surface does not exist. Check spelling."
+    parts = [bnd.surfaces[name] for name in bnd.surfaces if name in surfs]
+    pts = np.concatenate([s.points() for s in parts])
+    nrm = None if any(s.normals is None for s in parts) else np.concatenate([s.normals for s in parts])
+    areas = None if any(s.areas is None for s in parts) else np.concatenate([s.areas for s in parts])
+    for name in surfs:
+        del bnd.surfaces[name]
+    bnd.surfaces[surfs[0]] = PointSurface(pts, nrm, areas)
+    return None
+
+
 def split_surface(cloud, angle: float, target=None, k: int = 10, ctx=None):
     """split_surface!(cloud|boundary, [target], angle; k) (src/surface_operations.jl:33-94): splits a surface
     into the connected components of its k-NN graph restricted to edges whose normals differ by less than
