@@ -182,6 +182,9 @@ int wtp_relax_get_point_data(wtp_ctx* ctx, void* forces_out, void* nn_dist_out,
 int wtp_relax_set(wtp_ctx* ctx, int64_t i, const void* xyz);
 /* p .= p_old (src/repel.jl:314): undo the last sweep. */
 int wtp_relax_revert(wtp_ctx* ctx);
+/* wtp_relax_set for m movable points in one pass: idx strictly increasing, xyz m x dim of the session's
+ * dtype (the deposition pass of the octree method may land thousands of points in one iteration).  */
+int wtp_relax_set_batch(wtp_ctx* ctx, const int64_t* idx, const void* xyz, int64_t m);
 /* Refresh the PER_POINT spacing array (n values, snapshot order; repel.jl:251). */
 int wtp_relax_set_spacing(wtp_ctx* ctx, const void* spacing);
 /* Release the relax state (device buffers stay pooled in the context). */

@@ -316,3 +316,32 @@ def test_degenerate_triangles_and_exact_ties(ctx, O):
     got = ctx.mesh_query(np.array([(0.5, 0.3, 0.0)]))
     assert got["tri"][0] == -1 and not got["inside"][0] and np.isinf(got["sd"][0])
     ctx.mesh_clear()
+
+
+def test_set_points_batch(ctx, wtp):
+    """wtp_relax_set_batch == a loop of wtp_relax_set (used by the deposition pass)."""
+    rng = np.random.default_rng(9)
+    snap = rng.random((3000, 3)).astype(np.float32)
+    idx = np.sort(rng.choice(2900, 400, replace=False))
+    newp = rng.random((400, 3)).astype(np.float32)
+    outs = []
+    for batch in (True, False):
+        sess = ctx.relax(snap, 100, 0.07, dict(kind=2, beta=0.2, u0=1.0), 21, 1e-5, 1e-3)
+        try:
+            sess.step(True)
+            if batch:
+                sess.set_points(idx, newp)
+            else:
+                for i, p in zip(idx, newp):
+                    sess.set_point(int(i), p)
+            moved = sess.positions()
+            sess.step(True)
+            outs.append((moved, sess.positions()))
+            with pytest.raises(wtp.WtpArgumentError):
+                sess.set_points([5, 5], newp[:2])
+            with pytest.raises(wtp.WtpArgumentError):
+                sess.set_points([2900], newp[:1])
+        finally:
+            sess.close()
+    assert np.array_equal(outs[0][0][idx], newp)
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])

@@ -67,6 +67,7 @@ SIGNATURES = {
     "wtp_relax_get_point_data": (_i, [_vp, _vp, _vp, _vp]),
     "wtp_relax_set": (_i, [_vp, _i64, _vp]),
     "wtp_relax_revert": (_i, [_vp]),
+    "wtp_relax_set_batch": (_i, [_vp, _vp, _vp, _i64]),
     "wtp_relax_set_spacing": (_i, [_vp, _vp]),
     "wtp_relax_end": (_i, [_vp]),
     "wtp_relax_get_spacing": (_i, [_vp, _vp]),

@@ -1216,6 +1216,49 @@ WTP_API int wtp_relax_set(wtp_ctx* ctx, int64_t i, const void* xyz) {
     return sync(ctx);
 }
 
+// Many movable points placed at once (the deposition pass of the octree method lands a whole layer of
+// escapees in one iteration): idx ascending, strictly increasing; one pass over the snapshot.
+WTP_API int wtp_relax_set_batch(wtp_ctx* ctx, const int64_t* idx, const void* xyz, int64_t m) {
+    if (!ctx) return WTP_ERR_ARG;
+    RelaxState& r = ctx->relax;
+    if (!r.active) return fail(ctx, WTP_ERR_STATE, "wtp_relax_set_batch before wtp_relax_init");
+    if (m < 0) return fail(ctx, WTP_ERR_ARG, "m must be >= 0");
+    if (m == 0) return WTP_OK;
+    if (!idx || !xyz) return fail(ctx, WTP_ERR_ARG, "NULL array");
+    std::vector<int32_t> ids((size_t)m);
+    for (int64_t j = 0; j < m; ++j) {
+        if (idx[j] < 0 || idx[j] >= r.n - r.n_fixed) return fail(ctx, WTP_ERR_ARG, "movable point index out of range");
+        if (j > 0 && idx[j] <= idx[j - 1]) return fail(ctx, WTP_ERR_ARG, "indices must be strictly increasing");
+        ids[(size_t)j] = (int32_t)(idx[j] + r.n_fixed);
+    }
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rcf = flush_pending(ctx)) return rcf;
+    const size_t ts = tsize(r.dtype);
+    int rc;
+    const size_t o_v = (sizeof(int32_t) * (size_t)m + 255) / 256 * 256;
+    if ((rc = ensure(ctx, ctx->scratch, o_v + ts * (size_t)m * r.dim))) return rc;
+    if (r.bufP == r.bufS) { // P may alias the snapshot (fresh tree): give P its own buffer first (as wtp_relax_set)
+        const int t = pick_free(r, r.bufS, r.can_revert ? r.bufOld : -1);
+        if (t == r.bufS) return fail(ctx, WTP_ERR_STATE, "no free buffer for wtp_relax_set_batch");
+        const size_t ptsz = r.dtype == WTP_F32 ? sizeof(float4) : sizeof(double4);
+        if ((rc = ensure(ctx, ctx->pts[t], ptsz * (size_t)r.n))) return rc;
+        WTP_HIP(ctx, hipMemcpyAsync(ctx->pts[t].p, ctx->pts[r.bufP].p, ptsz * (size_t)r.n, hipMemcpyDeviceToDevice,
+                                    ctx->stream));
+        if (r.bufOld == t) r.can_revert = false;
+        r.bufP = t;
+    }
+    char* b = (char*)ctx->scratch.p;
+    WTP_HIP(ctx, hipMemcpyAsync(b, ids.data(), sizeof(int32_t) * (size_t)m, hipMemcpyHostToDevice, ctx->stream));
+    WTP_HIP(ctx, hipMemcpyAsync(b + o_v, xyz, ts * (size_t)m * r.dim, hipMemcpyHostToDevice, ctx->stream));
+    r.moved_by_hand = true;
+    rc = r.dtype == WTP_F32 ? launch_set_points<float>(ctx, (float4*)ctx->pts[r.bufP].p, r.n, (const int32_t*)b, m, r.dim,
+                                                       (const float*)(b + o_v))
+                            : launch_set_points<double>(ctx, (double4*)ctx->pts[r.bufP].p, r.n, (const int32_t*)b, m, r.dim,
+                                                        (const double*)(b + o_v));
+    if (rc) return rc;
+    return sync(ctx); // also keeps `ids` alive until the copy has run
+}
+
 WTP_API int wtp_relax_revert(wtp_ctx* ctx) {
     if (!ctx) return WTP_ERR_ARG;
     RelaxState& r = ctx->relax;

@@ -800,6 +800,36 @@ int launch_unpermute_point_data(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int64
     return WTP_OK;
 }
 
+// many points at once: ids ascending (snapshot ids), one binary search per snapshot point
+template <typename T>
+__global__ void set_points_kernel(Pt<T>* __restrict__ pts, int64_t n, const int32_t* __restrict__ ids, int64_t m, int dim,
+                                  const T* __restrict__ v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const int32_t id = w_to_id(pts[i].w);
+        int64_t lo = 0, hi = m;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (ids[mid] < id) lo = mid + 1;
+            else hi = mid;
+        }
+        if (lo < m && ids[lo] == id) {
+            pts[i].x = v[lo * dim];
+            pts[i].y = v[lo * dim + 1];
+            pts[i].z = dim == 3 ? v[lo * dim + 2] : (T)0;
+        }
+    }
+}
+
+template <typename T>
+int launch_set_points(wtp_ctx* ctx, Pt<T>* pts, int64_t n, const int32_t* d_ids, int64_t m, int dim, const T* d_v) {
+    hipLaunchKernelGGL(set_points_kernel<T>, dim3(grid_for(n, kThreads, 8192)), dim3(kThreads), 0, ctx->stream, pts, n, d_ids,
+                       m, dim, d_v);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
 template <typename T>
 int launch_set_point(wtp_ctx* ctx, Pt<T>* pts, int64_t n, int32_t id, int dim, const T* d_v) {
     hipLaunchKernelGGL(set_point_kernel<T>, dim3(grid_for(n, kThreads, 8192)), dim3(kThreads), 0,
@@ -1152,6 +1182,7 @@ int launch_refix(wtp_ctx* ctx, const Pt<T>* in, int64_t n_old, int64_t n_fixed_o
     template int launch_unpermute_point_data<T>(wtp_ctx*, const Pt<T>*, int64_t, int64_t, const T*,    \
                                                 const T*, const int32_t*, T*, T*, int32_t*);            \
     template int launch_set_point<T>(wtp_ctx*, Pt<T>*, int64_t, int32_t, int, const T*);                \
+    template int launch_set_points<T>(wtp_ctx*, Pt<T>*, int64_t, const int32_t*, int64_t, int, const T*); \
     template int launch_gen_uniform<T>(wtp_ctx*, uint64_t, int64_t, int64_t, int, T*);
 INST(float)
 INST(double)

@@ -332,6 +332,8 @@ int launch_unpermute_point_data(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int64
                                 const T* forces, const T* nn_dist, const int32_t* nn_id,
                                 T* forces_o, T* nn_dist_o, int32_t* nn_id_o);
 template <typename T>
+int launch_set_points(wtp_ctx* ctx, Pt<T>* pts, int64_t n, const int32_t* d_ids, int64_t m, int dim, const T* d_v);
+template <typename T>
 int launch_set_point(wtp_ctx* ctx, Pt<T>* pts, int64_t n, int32_t id, int dim, const T* d_xyz3);
 template <typename T>
 int launch_gen_uniform(wtp_ctx* ctx, uint64_t seed, int64_t first, int64_t n, int dim, T* d_out);

@@ -358,6 +358,12 @@ class RelaxSession:
         v = np.ascontiguousarray(xyz, dtype=self.dtype).reshape(self.dim)
         L.check(self.ctx._h, self._lib.wtp_relax_set(self.ctx._h, int(i), _vp(v)))
 
+    def set_points(self, idx, xyz):
+        """Place many movable points at once (indices strictly increasing)."""
+        idx = np.ascontiguousarray(idx, dtype=np.int64).reshape(-1)
+        v = np.ascontiguousarray(xyz, dtype=self.dtype).reshape(len(idx), self.dim)
+        L.check(self.ctx._h, self._lib.wtp_relax_set_batch(self.ctx._h, _vp(idx), _vp(v), len(idx)))
+
     def revert(self):
         L.check(self.ctx._h, self._lib.wtp_relax_revert(self.ctx._h))
 

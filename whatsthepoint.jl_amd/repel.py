@@ -238,6 +238,7 @@ def _deposit_escaped(sess, st, it, octree, spacing, deposit_ratio, offset, kq, c
     near = sess.query_knn(sites, kq)
     is_bnd, tri_all = w["is_bnd"].copy(), w["tri"].copy()
     n_dep = 0
+    placed = []
     for a, i in enumerate(ids):
         js = near[a].astype(np.int64)
         js = js[(js != i) & is_bnd[js]]
@@ -248,9 +249,10 @@ def _deposit_escaped(sess, st, it, octree, spacing, deposit_ratio, offset, kq, c
         p[i] = sites[a]
         is_bnd[i] = True
         tri_all[i] = tri[a]
-        sess.set_point(int(i), sites[a])
+        placed.append(a)
         n_dep += 1
     if n_dep:
+        sess.set_points(ids[placed], sites[placed])   # ids ascending: one pass over the snapshot
         sess.set_wall_flags(is_bnd, tri_all)
         log.debug("Deposited %d escaped point(s) onto the boundary at iteration %d", n_dep, it)
     return n_dep
