@@ -439,6 +439,15 @@ def main():
             out["roofline"]["traffic"] = round(tj["traffic_bytes_per_launch"] * pts_per_launch / tj["points_per_launch"])
             out["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
             out["roofline"]["algorithmic_bytes"] = round(B_ALG_SWEEP * pts_per_launch)
+            if "valu_wave_instructions_per_launch" in tj and sweep_ms > 0:
+                # what actually bounds the kernel: vector-ALU issue.  Wave instructions per launch from
+                # the committed SQ_INSTS_VALU pass, x 64 lanes, over the live launch time; peak = 256 CUs x 4 SIMDs x
+                # 16 lanes x 2.4 GHz (measured: tools/micro/valu_rate.hip).
+                ops = tj["valu_wave_instructions_per_launch"] * 64.0 * pts_per_launch / tj["points_per_launch"]
+                out["valu_issue"] = {"kernel": "wtp::brick_kernel<1,0,1>", "achieved": round(ops / (sweep_ms * 1e-3) / 1e12, 2),
+                                     "peak": 39.3, "unit": "T lane-ops/s", "frac": round(ops / (sweep_ms * 1e-3) / 39.3e12, 3),
+                                     "lane_ops_per_point": round(ops / pts_per_launch, 1),
+                                     "source": "profiles/r01_traffic.json (rocprofv3 --pmc SQ_INSTS_VALU)"}
         if full_sel is not None:
             out["full_k_selection_path"] = full_sel
         if world == 1 and not args.no_other_paths:
