@@ -43,6 +43,9 @@ for case in range(n_cases):
     rebuild_every = int(rng.choice([1, 1, 2]))
     force = dict(kind=kind, beta=0.2, u0=1.0, gamma=3.0)
     tag = f"case {case:3d} {np.dtype(dtype).name} dim={dim} n={n:6d} k={k:2d} law={kind} {layout:9s} nf={n_fixed:5d} pp={int(per_point)} re={rebuild_every}"
+    only = os.environ.get("FUZZ_ONLY")
+    if only is not None and case != int(only):
+        continue   # (the random stream above is consumed identically, so the case is reproduced exactly)
     try:
         # topology
         idx, dist = ctx.knn(x, k, return_dist=True)
@@ -71,8 +74,16 @@ for case in range(n_cases):
             pd = sess.point_data()
             ok_nn = np.array_equal(pd["nn_id"], ref["nn_id"]) and np.array_equal(pd["nn_dist"], ref["nn_dist"])
             fmax = float(ref["forces"].max()) if len(ref["forces"]) else 0.0
-            ok_f = abs(st["max_force"] - fmax) <= 1e-3 * max(fmax, 1e-30)
+            # (on an exact lattice the forces cancel to rounding noise: absolute floor of 1e-6 spacings)
+            ok_f = abs(st["max_force"] - fmax) <= 1e-3 * fmax + 1e-6 * s
             ok_s = ok_s and err <= tol and ok_nn and ok_f
+            if only is not None:
+                bad_id = np.nonzero(pd["nn_id"] != ref["nn_id"])[0]
+                bad_d = np.nonzero(pd["nn_dist"] != ref["nn_dist"])[0]
+                print(f"  it={it} rebuild={rebuild} err={err:.3e} tol={tol:.3e} ok_nn={ok_nn} ok_f={ok_f} max_force {st['max_force']} vs {fmax} "
+                      f"nn_id diffs {len(bad_id)} nn_dist diffs {len(bad_d)} fallback {st['n_fallback']}", flush=True)
+                for b in bad_id[:5]:
+                    print("    point", b, "gpu", pd["nn_id"][b], pd["nn_dist"][b], "oracle", ref["nn_id"][b], ref["nn_dist"][b], "pos", cur[n_fixed + b])
             cur[n_fixed:] = got
         sess.close()
         good = ok_t and ok_r and ok_s
