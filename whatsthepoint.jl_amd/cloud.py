@@ -48,6 +48,15 @@ class _HasTopology:
             return self._with(T.RadiusTopology(T.build_radius_neighbors(ctx, pts, param), param))
         raise TypeError("set_topology expects KNNTopology or RadiusTopology")
 
+    def _topo_line(self) -> str:
+        t = self.topology
+        return t.show().splitlines()[0] + "".join(" " + l.strip("├─└ ") for l in t.show().splitlines()[1:-1]) if hasattr(t, "show") else repr(t)
+
+    def __repr__(self):
+        """show(io, MIME"text/plain", x): a short tree naming the container, its size and its topology
+        (src/cloud.jl:239-272, src/surface.jl, src/volume.jl)."""
+        return f"{type(self).__name__}\n├─{len(self)} points\n└─topology: {self._topo_line()}\n"
+
     def rebuild_topology(self, ctx=None):
         """In place, same parameters; no-op for NoTopology (src/cloud.jl:224-228)."""
         if isinstance(self.topology, T.NoTopology):

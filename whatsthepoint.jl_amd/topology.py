@@ -16,6 +16,9 @@ class NoTopology(AbstractTopology):
     def __repr__(self):
         return "NoTopology()"
 
+    def show(self) -> str:
+        return "NoTopology\n"
+
 
 class KNNTopology(AbstractTopology):
     def __init__(self, neighbors, k: int):
