@@ -125,3 +125,96 @@ def test_knearestsearch_real_geometry_and_edge_cases(ctx, wtp):
     assert all(len(r) == 1 and r[0] == i for i, r in enumerate(rows))
     _, d = wtp.searchdists(c20, wtp.KNearestSearch(c20, 1), ctx=ctx)
     assert np.allclose(d[:, 0], 0.0, atol=1e-10)
+
+
+# ---- test/repel.jl items on the octree method (the input clouds come from `discretize` there — out of scope
+# here: a thinned boundary of the same surface + random interior points stand in) ----------------------------
+def _box_cloud(wtp, ctx, n_vol, seed, thin=40, dtype=np.float32):
+    z = np.load(os.path.join(GOLD, "box_mesh.npz"))
+    v, t = z["vertices"].astype(dtype), z["triangles"]
+    oc = wtp.TriangleOctree(v, t, ctx=ctx)
+    s = np.load(os.path.join(GOLD, "box_surface.npz"))
+    sel = np.arange(0, len(s["centroid"]), thin)
+    rng = np.random.default_rng(seed)
+    cand = (rng.random((4 * n_vol + 50, 3)) * 25).astype(dtype)
+    vol = cand[oc.isinside(cand)][:n_vol]
+    cloud = wtp.PointCloud(wtp.PointBoundary(s["centroid"][sel].astype(dtype), s["normal"][sel].astype(dtype),
+                                             s["area"][sel].astype(dtype)), wtp.PointVolume(vol))
+    return cloud, oc
+
+
+def test_repel_beta_kwarg_feeds_default_force_model(ctx, wtp):
+    """repel.jl:185-208"""
+    cloud, oc = _box_cloud(wtp, ctx, 300, 1)
+    sp = wtp.ConstantSpacing(3.1)
+    a = wtp.repel(cloud, sp, oc, beta=0.5, max_iters=5, ctx=ctx)
+    b = wtp.repel(cloud, sp, oc, force_model=wtp.ClippedSpacingForce(0.5), max_iters=5, ctx=ctx)
+    assert len(a) == len(b) and np.array_equal(a.points(), b.points())
+
+
+def test_repel_other_force_models_with_octree(ctx, wtp):
+    """repel.jl:210-260: SpacingEquilibriumForce / InverseDistanceForce keep every point and stay inside; the
+    equilibrium law leaves a cloud whose boundary and interior densities match the target at least as well
+    spaced as it started (the reference's weak invariant; it calls it tuning-dependent for the other law)."""
+    cloud, oc = _box_cloud(wtp, ctx, 880, 2, thin=84)          # ~2.6 apart on the surface and inside
+    sp = wtp.ConstantSpacing(2.6)
+    before = wtp.spacing_metrics(cloud, sp, k=10, ctx=ctx)
+    conv = []
+    c_eq = wtp.repel(cloud, sp, oc, force_model=wtp.SpacingEquilibriumForce(0.2), max_iters=40, convergence=conv, ctx=ctx)
+    assert len(c_eq) == len(cloud) and len(c_eq.volume) > 0 and np.isfinite(conv).all()
+    assert oc.isinside(c_eq.volume.points()).all()
+    assert wtp.spacing_metrics(c_eq, sp, k=10, ctx=ctx)["mean_error"] <= before["mean_error"] * 1.1
+    conv = []
+    c_inv = wtp.repel(cloud, sp, oc, force_model=wtp.InverseDistanceForce(0.2), max_iters=40, convergence=conv, ctx=ctx)
+    assert len(c_inv) == len(cloud) and np.isfinite(conv).all() and oc.isinside(c_inv.volume.points()).all()
+    assert np.isfinite(wtp.spacing_metrics(c_inv, sp, k=10, ctx=ctx)["mean_error"])
+
+
+def test_repel_stall_after_and_cv_target_with_octree(ctx, wtp):
+    """repel.jl:262-299"""
+    cloud, oc = _box_cloud(wtp, ctx, 400, 3)
+    sp = wtp.ConstantSpacing(2.8)
+    conv = []
+    wtp.repel(cloud, sp, oc, max_iters=200, tol=1e-12, stall_after=5, convergence=conv, ctx=ctx)
+    assert 5 < len(conv) < 200
+    conv_t = []
+    c_t = wtp.repel(cloud, sp, oc, max_iters=200, tol=1e-12, cv_target=10.0, convergence=conv_t, ctx=ctx)
+    assert len(conv_t) == 1 and np.array_equal(c_t.points(), cloud.points())
+    conv_off = []
+    wtp.repel(cloud, sp, oc, max_iters=30, tol=1e-12, stall_after=0, convergence=conv_off, ctx=ctx)
+    assert len(conv_off) == 30
+
+
+def test_repel_cull_kick_trace_rebuild_every(ctx, wtp):
+    """repel.jl:375-470"""
+    z = np.load(os.path.join(GOLD, "box_mesh.npz"))
+    oc = wtp.TriangleOctree(z["vertices"], z["triangles"], ctx=ctx)
+    s = np.load(os.path.join(GOLD, "box_surface.npz"))
+    rng = np.random.default_rng(4)
+    vol = (rng.random((4000, 3)) * 24.6 + 0.2).astype(np.float32)
+    full = wtp.PointCloud(wtp.PointBoundary(s["centroid"], s["normal"], s["area"]), wtp.PointVolume(vol))
+    sp = wtp.ConstantSpacing(0.25)                     # consistent with the tessellation (face centres ~0.22 apart)
+    nocull = wtp.repel(full, sp, oc, max_iters=20, ctx=ctx)
+    culled = wtp.repel(full, sp, oc, max_iters=20, cull_ratio=0.5, ctx=ctx)
+    assert len(culled) <= len(nocull)
+    m = wtp.metrics(culled, k=2, ctx=ctx)
+    assert m["separation"] >= 0.5 * 0.25 * (1 - 1e-6)
+    cloud, oc2 = _box_cloud(wtp, ctx, 300, 5)
+    sp = wtp.ConstantSpacing(3.1)
+    kicked = wtp.repel(cloud, sp, oc2, max_iters=30, kick_after=5, ctx=ctx)
+    assert len(kicked.volume) > 0 and len(kicked) == len(cloud)
+    # the volume-only method needs the whole surface for its isinside filter: the full boundary again
+    sp = wtp.ConstantSpacing(0.25)
+    traces = []
+    wtp.repel(full, sp, max_iters=5, trace=traces, ctx=ctx)
+    assert len(traces) == 5 and all(t["r_over_s"] > 0 and "idx_a" in t and "idx_b" in t for t in traces)
+    c3 = wtp.repel(full, sp, max_iters=10, rebuild_every=3, ctx=ctx)
+    assert len(c3.volume) > 0
+    with pytest.raises(wtp.WtpArgumentError):
+        wtp.repel(full, sp, rebuild_every=0, ctx=ctx)
+    # 2-D clouds, a kick on the first iteration (repel.jl:417-432)
+    corners = np.array([(0.0, 0.0), (1.0, 0.0), (1.0, 1.0), (0.0, 1.0)])
+    inner = rng.random((40, 2)) * 0.8 + 0.1
+    c2 = wtp.repel(wtp.PointCloud(wtp.PointBoundary(corners), wtp.PointVolume(inner)), wtp.ConstantSpacing(0.2), max_iters=3,
+                   kick_after=1, ctx=ctx)
+    assert c2.points().shape[1] == 2
