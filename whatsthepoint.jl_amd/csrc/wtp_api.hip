@@ -935,8 +935,8 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
         // law's support u0*s and the nearest-neighbour radius, so they can be smaller than the k-NN
         // cells (rho ~ 3.5 instead of ~8): 2.3x fewer candidates per query.
         r.cs_sweep = r.force.kind == WTP_FORCE_CLIPPED_SPACING && r.k >= 2 && r.k < 32 && !ctx->full_select &&
-                     !ctx->force_generic;
-        const double rho_cs = r.cs_sweep ? 3.5 * (ctx->rho / 8.0) : 0.0;
+                     !ctx->force_generic && !r.cs_disabled;
+        double rho_cs = r.cs_sweep ? 3.5 * (ctx->rho / 8.0) : 0.0;
         if (r.spacing_typ <= 0) { // once per session: the spacing a typical point asks for
             r.spacing_typ = r.spacing_const;
             if (r.spacing_kind != WTP_SPACING_CONSTANT) {
@@ -955,14 +955,31 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
         // spacing the cell edge follows the spacing a typical point asks for (the mean over points, which
         // the dense regions dominate), not the largest one: the few points whose support is wider than
         // that are handed to the exact path, instead of everybody's cells being 64x over-full.
-        const double min_cell = r.cs_sweep ? 1.1 * r.force.u0 * (r.spacing_typ < r.spacing_max ? r.spacing_typ : r.spacing_max)
-                                           : 0.0;
+        double min_cell = r.cs_sweep ? 1.1 * r.force.u0 * (r.spacing_typ < r.spacing_max ? r.spacing_typ : r.spacing_max)
+                                     : 0.0;
         if (!r.grid_tuned) { // once per session: measured cell edge, LDS point area sized from the real grid
             double rho_eff = 0;
             Grid<T> hg;
             rc = build_hash_tuned<T>(ctx, (const Pt<T>*)ctx->pts[r.bufP].p, (Pt<T>*)ctx->pts[t].p, r.n, r.dim, r.k, 0.0,
                                      rho_cs, min_cell, &r.cell_scale, &rho_eff, &hg);
             if (rc) return rc;
+            // A spacing far coarser than the cloud (the reference's own tests repel 46 786 face centres 0.22 apart
+            // with a spacing of 3): cells that cover the law's support then hold hundreds of points, every support
+            // ball holds more than k of them and each query would go to the exact path one by one.  Such a session
+            // takes the k-selection sweep on cells sized for the k-th neighbour instead (same results).  Only when
+            // the crowded points are themselves queries: a dense FIXED wall around a few movable points is served
+            // well by the support cells (their balls hold few points), and badly by small cells (the movable
+            // points' k-th neighbour is many cells away).
+            if (r.cs_sweep && rho_eff > 4.0 * rho_cs && 2 * r.n_fixed < r.n) {
+                r.cs_disabled = true;
+                r.cs_sweep = false;
+                rho_cs = 0.0;
+                min_cell = 0.0;
+                r.cell_scale = 1.0;
+                rc = build_hash_tuned<T>(ctx, (const Pt<T>*)ctx->pts[r.bufP].p, (Pt<T>*)ctx->pts[t].p, r.n, r.dim, r.k, 0.0,
+                                         rho_cs, min_cell, &r.cell_scale, &rho_eff, &hg);
+                if (rc) return rc;
+            }
             if (r.cs_sweep) {
                 int hc = (int)(HCELLS * rho_eff * 1.15) + 128;
                 hc = (hc + 63) / 64 * 64;

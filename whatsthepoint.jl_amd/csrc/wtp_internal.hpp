@@ -166,6 +166,7 @@ struct RelaxState {
     double cell_scale = 1.0; // < 1: cells shrunk because the occupied ones hold more than the box average
     double spacing_typ = 0;  // mean spacing over the snapshot (floor of the compact-support cell edge)
     bool cs_sweep = false;   // compact-support sweep in use (ClippedSpacingForce)
+    bool cs_disabled = false; // measured on the first rebuild: support cells would be over-full, use the k-selection sweep
     double sp_p0 = 0, sp_p1 = 0, sp_p2 = 0; // LOGLIKE / BOUNDARY_LAYER parameters
     HashView pending;        // wtp_relax_set_fixed_dev left its work to the next rebuild (see there)
     int64_t shard_extra = 0; // extra capacity of the point buffers once the fixed head gets replaced
