@@ -431,6 +431,27 @@ def main():
                 "fallback_reduce": round(tm["other_ms"] / args.steps, 4),
             },
         }
+        if world == 1:
+            # next to the 8 TB/s spec figure, the copy bandwidth this box actually delivers
+            # (a 1 GiB device-to-device copy: read + write), and the fraction against it
+            try:
+                src = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+                dst = torch.empty_like(src)
+                dst.copy_(src)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    dst.copy_(src)
+                e1.record()
+                torch.cuda.synchronize()
+                copy_gbs = 2.0 * src.numel() * 4 * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+                out["roofline"]["measured_copy_gbs"] = round(copy_gbs, 1)
+                out["roofline"]["frac_of_measured_copy"] = round(achieved / copy_gbs, 5)
+                del src, dst
+            except Exception as e:  # measurement aid only
+                out["roofline"]["measured_copy_gbs"] = None
+                print(f"[bench] copy-bandwidth probe failed: {e}", file=sys.stderr)
         # HBM bytes per launch come from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 on
         # gfx950 + WRITE_SIZE), scaled to this launch's point count; counters cannot be read live.
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
