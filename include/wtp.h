@@ -327,7 +327,7 @@ int wtp_timers_get(wtp_ctx* ctx, double out[4]);
 int wtp_timers_reset(wtp_ctx* ctx);
 /* Diagnostic builds only (-DWTP_DIAG=1): per-phase wave-cycle sums of the sweep kernel since the last
  * call ([0..6] phases, [7] waves); release builds return zeros.  tools/exp_diag.py. */
-int wtp_debug_diag(wtp_ctx* ctx, unsigned long long out[8]);
+int wtp_debug_diag(wtp_ctx* ctx, unsigned long long out[16]);
 
 /* Synthetic workload generator of SURVEY.md §8d, written straight into device memory:
  * value(i, axis) = (splitmix64(seed*2^40 + 3*(first+i) + axis) >> 40) * 2^-24.

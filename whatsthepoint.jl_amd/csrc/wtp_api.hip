@@ -450,6 +450,8 @@ WTP_API int wtp_create(const int* device_ordinals, int n_dev, wtp_ctx** out) {
     if (const char* e = getenv("WTP_TNN")) ctx->tnn_frac = atof(e) > 0 && atof(e) < 0.99 ? atof(e) : ctx->tnn_frac;
     if (const char* e = getenv("WTP_FORCE_GENERIC")) ctx->force_generic = atoi(e);
     if (const char* e = getenv("WTP_FULL_SELECT")) ctx->full_select = atoi(e);
+    if (const char* e = getenv("WTP_CS2")) ctx->cs2 = atoi(e);
+    if (const char* e = getenv("WTP_RHO_CS")) ctx->rho_cs2 = atof(e) >= 1.0 ? atof(e) : ctx->rho_cs2;
     if (const char* e = getenv("WTP_STYP_SIGMA")) ctx->styp_sigma = atof(e);
     if (const char* e = getenv("WTP_TIMING")) ctx->timing = atoi(e) != 0;
     if (const char* e = getenv("WTP_MESH_PACKET")) ctx->mesh_packet = atoi(e);
@@ -466,7 +468,7 @@ WTP_API int wtp_destroy(wtp_ctx* ctx) {
                       &ctx->cell_cnt, &ctx->cell_start, &ctx->scan_tmp, &ctx->grid, &ctx->bbox_part,
                       &ctx->idx_out, &ctx->dist_out, &ctx->counts_out, &ctx->forces, &ctx->nn_dist,
                       &ctx->nn_id, &ctx->spacing_pp, &ctx->partials, &ctx->stats, &ctx->fb_list,
-                      &ctx->fb_count, &ctx->fb2_list, &ctx->fb2_count, &ctx->scratch, &ctx->diag,
+                      &ctx->fb_count, &ctx->fb2_list, &ctx->fb2_count, &ctx->nn_list, &ctx->scratch, &ctx->diag,
                       &ctx->ins_in, &ctx->ins_elems, &ctx->ins_partial, &ctx->ins_out, &ctx->mesh_nodes, &ctx->mesh_pn, &ctx->mesh_io,
                       &ctx->wall_flags, &ctx->wall_tri, &ctx->wall_hint, &ctx->mesh_cls, &ctx->kd_nodes, &ctx->sp_hint, &ctx->occ, &ctx->box_dev,
                       &ctx->cand_idx, &ctx->cand_dist, &ctx->f32_pts};
@@ -921,6 +923,67 @@ WTP_API int wtp_relax_init_dev(wtp_ctx* ctx, const void* d_snap_xyz, int64_t n, 
     return relax_init_impl(ctx, d_snap_xyz, true, n, n_fixed, dim, dtype, spacing, force, k, alpha_lo, alpha_max);
 }
 
+// Brick geometry of the round-2 compact-support sweep (wtp_cs2.hip), from a census of the grid just built:
+// the brick length BX is set so that 97 % of the non-empty bricks hold at most ~244 queries (one round of
+// the 256-thread workgroup) and the LDS point area so that 99.9 % of the halos fit; the rest takes a second
+// round / the exact path.  Two or three tiny launches and read-backs, once per session.
+static int cs2_tune(wtp_ctx* ctx, RelaxState& r, const Grid<float>& hg, double rho_eff) {
+    int rc;
+    if ((rc = ensure(ctx, ctx->occ, 513 * sizeof(unsigned int)))) return rc;
+    if ((rc = ensure_pinned(ctx, 16384))) return rc;
+    const double cells = (double)hg.n[0] * hg.n[1] * hg.n[2];
+    double rho_est = cells > 0 ? (double)r.n / cells : 1.0;
+    if (rho_eff - 1.0 > rho_est) rho_est = rho_eff - 1.0;
+    if (rho_est < 0.25) rho_est = 0.25;
+    const int bx_max = hg.n[0] < cs2_max_bx() ? (hg.n[0] < 1 ? 1 : hg.n[0]) : cs2_max_bx();
+    auto clampbx = [&](double v) {
+        int b = (int)(v + 0.5);
+        return b < 2 ? (bx_max < 2 ? bx_max : 2) : (b > bx_max ? bx_max : b);
+    };
+    int bx = clampbx(220.0 / (4.0 * rho_est));
+    int q97 = 0, h999 = 0;
+    for (int it = 0; it < 4; ++it) {
+        if ((rc = launch_cs2_census(ctx, bx, (unsigned int*)ctx->occ.p))) return rc;
+        WTP_HIP(ctx, hipMemcpyAsync(ctx->host_pinned, ctx->occ.p, 513 * sizeof(unsigned int), hipMemcpyDeviceToHost,
+                                    ctx->stream));
+        if ((rc = sync(ctx))) return rc;
+        const unsigned int* h = (const unsigned int*)ctx->host_pinned;
+        const double nb = (double)h[512];
+        auto quant = [&](int base, double frac, int width) {
+            double run = 0;
+            for (int b = 0; b < 256; ++b) {
+                run += h[base + b];
+                if (run >= frac * nb) return (b + 1) * width;
+            }
+            return 256 * width;
+        };
+        q97 = nb > 0 ? quant(0, 0.97, 2) : 0;
+        h999 = nb > 0 ? quant(256, 0.999, 8) : 0;
+        if (nb <= 0) break;
+        // queries: aim at 236 for the 97th percentile; halo: at most ~1060 points (four workgroups per CU)
+        double f = 1.0;
+        if (q97 > 248 || q97 < 216) f = 236.0 / (double)q97;
+        if (h999 * f > 1060.0) f = 1060.0 / (double)h999;
+        const int nbx = clampbx(bx * f);
+        if (nbx == bx || it == 3) break;
+        bx = nbx;
+    }
+    // equal bricks along x: n[0] = 214 cells cut into bricks of 51 leaves a fifth brick of 10 cells that pays the
+    // whole per-brick setup for a fifth of the work; cut into ceil(n/bx) equal parts instead (never longer)
+    if (hg.n[0] > bx) {
+        const int parts = (hg.n[0] + bx - 1) / bx;
+        bx = (hg.n[0] + parts - 1) / parts;
+    }
+    int hc = (int)(h999 * 1.05) + 48;
+    hc = (hc + 63) / 64 * 64;
+    r.brick_hcap = hc < 256 ? 256 : (hc > 1920 ? 1920 : hc);
+    r.cs2_bx = bx;
+    if (getenv("WTP_DEBUG"))
+        fprintf(stderr, "[wtp] cs2 geometry: BX=%d hcap=%d (q97=%d h999=%d rho_est=%.3f grid %dx%dx%d c=%g)\n", bx,
+                r.brick_hcap, q97, h999, rho_est, hg.n[0], hg.n[1], hg.n[2], (double)hg.c);
+    return WTP_OK;
+}
+
 template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_step_stats* d_slot) {
     RelaxState& r = ctx->relax;
     int rc;
@@ -936,7 +999,10 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
         // cells (rho ~ 3.5 instead of ~8): 2.3x fewer candidates per query.
         r.cs_sweep = r.force.kind == WTP_FORCE_CLIPPED_SPACING && r.k >= 2 && r.k < 32 && !ctx->full_select &&
                      !ctx->force_generic && !r.cs_disabled;
-        double rho_cs = r.cs_sweep ? 3.5 * (ctx->rho / 8.0) : 0.0;
+        // round-2 sweep (wtp_cs2.hip, fp32 3-D): the nearest neighbour comes from the support or from a
+        // per-wave follow-up, so the cells only cover the support: rho ~ 1
+        const bool cs2 = r.cs_sweep && ctx->cs2 && sizeof(T) == 4 && r.dim == 3;
+        double rho_cs = r.cs_sweep ? (cs2 ? ctx->rho_cs2 : 3.5 * (ctx->rho / 8.0)) : 0.0;
         if (r.spacing_typ <= 0) { // once per session: the spacing a typical point asks for
             r.spacing_typ = r.spacing_const;
             if (r.spacing_kind != WTP_SPACING_CONSTANT) {
@@ -955,7 +1021,9 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
         // spacing the cell edge follows the spacing a typical point asks for (the mean over points, which
         // the dense regions dominate), not the largest one: the few points whose support is wider than
         // that are handed to the exact path, instead of everybody's cells being 64x over-full.
-        double min_cell = r.cs_sweep ? 1.1 * r.force.u0 * (r.spacing_typ < r.spacing_max ? r.spacing_typ : r.spacing_max)
+        // (constant spacing: c - margin = c (1 - 1/256) must reach u0 s, 1.01 does; variable: 10 % headroom over the mean)
+        const double cell_f = (cs2 && r.spacing_kind == WTP_SPACING_CONSTANT) ? 1.01 : 1.1;
+        double min_cell = r.cs_sweep ? cell_f * r.force.u0 * (r.spacing_typ < r.spacing_max ? r.spacing_typ : r.spacing_max)
                                      : 0.0;
         if (!r.grid_tuned) { // once per session: measured cell edge, LDS point area sized from the real grid
             double rho_eff = 0;
@@ -970,7 +1038,7 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
             // the crowded points are themselves queries: a dense FIXED wall around a few movable points is served
             // well by the support cells (their balls hold few points), and badly by small cells (the movable
             // points' k-th neighbour is many cells away).
-            if (r.cs_sweep && rho_eff > 4.0 * rho_cs && 2 * r.n_fixed < r.n) {
+            if (r.cs_sweep && rho_eff > (cs2 ? 5.0 : 4.0 * rho_cs) && 2 * r.n_fixed < r.n) {
                 r.cs_disabled = true;
                 r.cs_sweep = false;
                 rho_cs = 0.0;
@@ -980,12 +1048,18 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
                                          rho_cs, min_cell, &r.cell_scale, &rho_eff, &hg);
                 if (rc) return rc;
             }
-            if (r.cs_sweep) {
+            r.cs2_bx = 0;
+            if (r.cs_sweep && cs2) {
+                Grid<float> hgf;
+                memcpy(&hgf, &hg, sizeof(hgf)); // T == float here
+                if ((rc = cs2_tune(ctx, r, hgf, rho_eff))) return rc;
+            } else if (r.cs_sweep) {
                 int hc = (int)(HCELLS * rho_eff * 1.15) + 128;
                 hc = (hc + 63) / 64 * 64;
                 r.brick_hcap = hc < 640 ? 640 : (hc > 2560 ? 2560 : hc);
             }
             r.grid_tuned = true;
+            r.tuned_fixed = r.n_fixed;
             r.grid_age = 0;
         } else {
             // The bounding box moves by at most a spacing per sweep: it is recomputed every few rebuilds only
@@ -1050,9 +1124,16 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
     // one 64-byte counter block, cleared once per sweep: [0] hand-backs of the brick kernel,
     // [4] of the wave kernel, [8] uncovered queries
     a.fb2_count = (int32_t*)ctx->fb_count.p + 4;
+    a.nn_list = nullptr;
+    a.nn_count = (int32_t*)ctx->fb_count.p + 2;
+    if (r.cs_sweep && r.cs2_bx > 0) {
+        if ((rc = ensure(ctx, ctx->nn_list, sizeof(int32_t) * (size_t)r.n))) return rc;
+        a.nn_list = (int32_t*)ctx->nn_list.p;
+    }
     if ((rc = ensure(ctx, ctx->diag, 128))) return rc;
     a.diag = (unsigned long long*)ctx->diag.p;
     a.brick_hcap = r.cs_sweep ? r.brick_hcap : 0;
+    a.cs2_bx = r.cs_sweep ? r.cs2_bx : 0;
     a.tnn_frac = (T)ctx->tnn_frac;
     a.cover_axis = r.cover_axis;
     a.cover_lo = (T)r.cover_lo;
@@ -1631,6 +1712,13 @@ WTP_API int wtp_relax_set_fixed_dev(wtp_ctx* ctx, const void* d_fixed4, int64_t 
         if (rc) return rc;
         r.bufP = t;
     }
+    // The brick geometry of the round-2 sweep (and which queries its bricks hand to the exact path, whose sums
+    // round differently) was measured on the cloud of the first rebuild: a head that changes the cloud by more
+    // than 5 % has it measured again, so that a resident session keeps equalling a fresh one bit for bit.
+    if (r.cs2_bx > 0 && std::llabs((long long)(n_fixed_new - r.tuned_fixed)) * 20 > (long long)n_new) {
+        r.grid_tuned = false;
+        r.cell_scale = 1.0;
+    }
     r.n = n_new;
     r.n_fixed = n_fixed_new;
     r.k = (int64_t)r.k_req < n_new ? r.k_req : (int)n_new;
@@ -1677,12 +1765,12 @@ WTP_API int wtp_timers_reset(wtp_ctx* ctx) {
 
 // Diagnostic builds (-DWTP_DIAG): per-phase wave-cycle sums of the brick kernel, accumulated
 // over all launches since the last call; reading resets them.  Release builds leave zeros.
-WTP_API int wtp_debug_diag(wtp_ctx* ctx, unsigned long long out[8]) {
+WTP_API int wtp_debug_diag(wtp_ctx* ctx, unsigned long long out[16]) {
     if (!ctx || !out) return WTP_ERR_ARG;
     WTP_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
     if ((rc = ensure(ctx, ctx->diag, 128))) return rc;
-    WTP_HIP(ctx, hipMemcpyAsync(out, ctx->diag.p, 64, hipMemcpyDeviceToHost, ctx->stream));
+    WTP_HIP(ctx, hipMemcpyAsync(out, ctx->diag.p, 128, hipMemcpyDeviceToHost, ctx->stream));
     WTP_HIP(ctx, hipMemsetAsync(ctx->diag.p, 0, 128, ctx->stream));
     return sync(ctx);
 }

@@ -823,7 +823,7 @@ template <int MODE, int KT, int CS> static int brick_launch(wtp_ctx* ctx, Search
     return WTP_OK;
 }
 
-int brick_partials() { return 256 * 4 + 8; }
+int brick_partials() { return 4096 + 8 + 256; } // + the follow-up kernel of the round-2 sweep (wtp_cs2.hip)
 
 // RadiusTopology through the brick kernel (fp32): rows of up to 32 entries are counted / sorted and written
 // here, the rest (longer rows, queries the 27 cells cannot certify, bricks too large for LDS) is appended
@@ -863,7 +863,7 @@ template <> int launch_sweep<float>(wtp_ctx* ctx, SearchArgs<float>& a, bool fre
     // WTP_FULL_SELECT=1 asks for the explicit k-selection on every query (both give the same output)
     // (the caller sized the grid for it and says so by passing the LDS point capacity)
     const bool cs = a.brick_hcap > 0 && a.force_kind == WTP_FORCE_CLIPPED_SPACING && a.k >= 2 && !ctx->full_select;
-    int rc = cs ? brick_launch<1, 0, 1>(ctx, a)
+    int rc = cs ? (a.cs2_bx > 0 ? launch_cs2(ctx, a) : brick_launch<1, 0, 1>(ctx, a))
                 : (a.k == 21 ? brick_launch<1, 21, 0>(ctx, a) : brick_launch<1, 0, 0>(ctx, a));
     span_end(ctx, sp);
     if (rc) return rc;

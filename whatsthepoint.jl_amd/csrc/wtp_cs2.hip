@@ -1,0 +1,736 @@
+// wtp_cs2.hip — the default repel sweep (round 2): ClippedSpacingForce on fp32 3-D clouds.
+//
+// What it computes is the body of `_relax!`'s sweep closure (src/repel.jl:256-292) with the force
+// law of src/repel_forces.jl:96-100, exactly like brick_kernel<1,0,1> (wtp_brick.hip), whose
+// compact-support argument it keeps: the clipped law is 0 for r >= u0*s, so when the support ball
+// holds n_lim <= k points they ARE among the k nearest and the sum over them equals the reference's
+// sum over its k-list, term for term.  What is new is everything around that argument:
+//
+//   * the nearest neighbour no longer rides on a margin of the ring.  If the support holds another
+//     point, the nearest of them is the global nearest (everything outside is farther).  The ~1.5 % of
+//     the queries whose support is empty are finished by their own wave after the brick's queries: 64
+//     lanes scan the query's 27 cells cooperatively (staged in LDS already), a lexicographic
+//     (d2, id) minimum over the wave, certified against the provable radius; the few that even the 27
+//     cells cannot certify go to the exact path.  So the cells only have to cover the support:
+//     c = 1.01 u0 s instead of 1.52 s — rho ~ 1 point per cell instead of 3.5, 28 candidates in the 27
+//     cells instead of 95;
+//   * bricks are BX x 2 x 2 cells (BX ~ 56) and the halo is staged in LDS in (hx, hz, hy) order —
+//     x SLOWEST.  A query's 3x3x3 neighbourhood is then ONE contiguous run of 43 halo cells (its 27
+//     plus 16 cells two rows away in y or z, whose points fail the distance test by construction), so
+//     the scan is a single loop over ~44 consecutive LDS slots: no rows, no run table, no queue;
+//   * global loads stay coalesced: a halo x-row is one contiguous run of the sorted array, the
+//     permutation happens in the LDS store (destination = start of the point's cell + its rank).
+//
+// Everything the fast path cannot certify — support wider than the provable radius (variable
+// spacing), more than k points inside the support, a coincident neighbour (r = 0 needs the
+// substitute direction), ring or LDS overflow — is appended to a.fb_list for the exact wave path,
+// so results are always the exact sums.
+//
+// Roofline: 16 B/point in, 28 B/point out; ~1.3 k VALU lane-ops per query.
+#include "wtp_device.hpp"
+
+namespace wtp {
+
+#ifndef WTP_DIAG
+#define WTP_DIAG 0 // diagnostic build: s_memtime stamps per phase + loop-trip counts (never quote its run time)
+#endif
+#define CS_STAMP(i)                                                 \
+    if (WTP_DIAG) {                                                 \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        dt[i] += t_ - t_last;                                       \
+        t_last = t_;                                                \
+    }
+
+constexpr int kCsThreads = 256;
+constexpr int kCsSlab = 16;                         // halo cells per x index: (2+2) x (2+2)
+constexpr int kCsMaxBX = 61;                        // own cells along x; halo + the closing column <= 64 lanes
+constexpr int kCsMaxCells = (kCsMaxBX + 2) * kCsSlab;
+constexpr int kCsRing = 24;                         // ring entries per lane (hits inside the support; > k of them -> exact path)
+constexpr int kCsRingStride = 36;                   // bytes per lane: 24 entries + 8 a scan step may still store + pad; 9 dwords: odd, so lanes spread over the banks
+constexpr int kCsSU = 8;                            // candidates per scan step
+constexpr int kCsPadBytes = kCsSU * 16;
+constexpr int kCsMaxQ = 512;                        // queries per brick the lane table covers
+constexpr int kCsMiss = 16;                         // empty-support queries per wave per brick
+constexpr int kCsRun = 2 * kCsSlab + 2 * 4 + 3;     // halo cells in a query's run: 43
+
+struct CsMiss {
+    uint32_t pa, ea, qoff; // candidate run and the query's own slot (byte offsets into the point area)
+    int32_t gslot, qid;
+    float f, s, g2;
+};
+
+struct Cs2Smem {
+    uint32_t hglobal[kCsMaxCells];   // index in the sorted array of the first point of each halo cell
+    uint16_t ls[kCsMaxCells + 4];    // LDS slot of the first point of each halo cell, (hx, hz, hy) order
+    uint16_t qpref[kCsMaxBX + 2];    // first query of each own slab
+    uint8_t qslab[kCsMaxQ];          // slab (hx) of each query
+    // per wave (= four halo x-rows) and per column hx: sum of cell_start, sum of the cells' counts, and
+    // (waves 1, 2) the sum of cell_start over the two own rows: every prefix the brick needs is a difference of these
+    uint32_t wsum[4][64], wcnt[4][64], wown[2][64];
+    int scan_tmp[kCsThreads / 64 + 1];
+    int miss_n[kCsThreads / 64];
+    CsMiss miss[kCsThreads / 64][kCsMiss];
+    Acc acc[kCsThreads / 64];
+};
+
+typedef float cs_f4 __attribute__((ext_vector_type(4)));
+
+// Per-lane statistics in 9 registers instead of Acc's 14 (same values: a float compared as float or as the
+// double it converts to orders the same; the sums stay in double like acc_point's)
+struct CsAcc {
+    float max_force, argmin_r;
+    double sum_u, sum_u2;
+    int32_t argmin_i, argmin_j, n_move;
+};
+__device__ inline void cs_acc_point(CsAcc& c, float force, float nd, float s, int32_t id, int32_t nn) {
+    c.max_force = force > c.max_force ? force : c.max_force;
+    const double u = (double)(nd / s);
+    c.sum_u += u;
+    c.sum_u2 += u * u;
+    c.n_move += 1;
+    if (nd < c.argmin_r || (nd == c.argmin_r && id < c.argmin_i)) {
+        c.argmin_r = nd;
+        c.argmin_i = id;
+        c.argmin_j = nn;
+    }
+}
+
+// ClippedSpacingForce (src/repel_forces.jl:96-100) on u2 = d2 / s^2, fast reciprocal (1 ulp), the same
+// expression as brick_kernel's force_fast with (A, B, lo) = (u0^2, 1, 0)
+struct ForceCoefCs {
+    float A, beta;
+};
+__device__ inline ForceCoefCs force_coef_cs(float beta, float u0) { return ForceCoefCs{u0 * u0, beta}; }
+__device__ inline float force_fast_cs(const ForceCoefCs& c, float u2) {
+    const float d = u2 + c.beta;
+    const float inv = __builtin_amdgcn_rcpf(d * d);
+    const float f = (c.A - u2) * inv;
+    return f > 0.f ? f : 0.f;
+}
+
+// four consecutive staged points: explicit ds_read_b128 (the compiler would shrink the loads to b96 when .w
+// is unused, which costs twice the LDS cycles per instruction) and a single wait
+template <int OFF> __device__ inline void cs_read_group(cs_f4 (&c)[4], uint32_t addr) {
+    asm volatile(
+        "ds_read_b128 %0, %4 offset:%5\n\t"
+        "ds_read_b128 %1, %4 offset:%6\n\t"
+        "ds_read_b128 %2, %4 offset:%7\n\t"
+        "ds_read_b128 %3, %4 offset:%8\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3])
+        : "v"(addr), "n"(OFF), "n"(OFF + 16), "n"(OFF + 32), "n"(OFF + 48)
+        : "memory");
+}
+
+__device__ inline float4 cs_pt(const unsigned char* base, uint32_t byte_off) {
+    return *reinterpret_cast<const float4*>(base + byte_off);
+}
+
+static size_t cs2_smem_bytes(int hcap) {
+    return (size_t)hcap * 16 + kCsPadBytes + (size_t)kCsRingStride * kCsThreads + sizeof(Cs2Smem);
+}
+
+__global__ __launch_bounds__(kCsThreads, 4) void cs2_kernel(SearchArgs<float> a, int hcap, int BX) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float4* pts = reinterpret_cast<float4*>(smem_raw);
+    const uint32_t ring_off = (uint32_t)hcap * 16u + (uint32_t)kCsPadBytes;
+    Cs2Smem* sm = reinterpret_cast<Cs2Smem*>(smem_raw + ring_off + (size_t)kCsRingStride * kCsThreads);
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave-uniform by construction; saying so keeps the per-row geometry and the row bounds in scalar registers
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const Grid<float> g = *a.grid;
+    const int K = a.k;
+    const int HX = BX + 2, ncell = HX * kCsSlab;
+    const int nbx = (g.n[0] + BX - 1) / BX, nby = (g.n[1] + 1) / 2, nbz = (g.n[2] + 1) / 2;
+    const int nbricks = nbx * nby * nbz;
+    CsAcc acc;
+    acc.max_force = 0.f;
+    acc.argmin_r = Lim<float>::inf();
+    acc.sum_u = acc.sum_u2 = 0.0;
+    acc.argmin_i = acc.argmin_j = -1;
+    acc.n_move = 0;
+    unsigned long long dt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_last = WTP_DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
+
+    // constant spacing: everything that depends on s only is wave-uniform
+    const float s_c = a.spacing_const, inv_s2_c = 1.f / (s_c * s_c), lim_c = (a.u0 * a.u0) * (s_c * s_c);
+    const float gmin = g.c - g.margin;
+    const bool const_ok = !a.spacing_pp && gmin > 0.f && lim_c <= gmin * gmin; // smallest provable radius covers the support
+
+    // XCD-aware brick order (blocks sharing blockIdx % 8 share an L2): one contiguous slab of bricks each
+    const int groups = 8;
+    const int per = (nbricks + groups - 1) / groups;
+    const int xcd = blockIdx.x % groups;
+    const int lane_blk = blockIdx.x / groups;
+    const int blk_per_group = gridDim.x / groups;
+    const int b_end = (xcd + 1) * per < nbricks ? (xcd + 1) * per : nbricks;
+
+    // The loads of a brick are issued one brick ahead and sit in registers while the previous brick's queries
+    // run (waited for in place they are two dependent global round trips, ~40 % of a wave's time when measured):
+    //   top of brick i    the cell-table loads of brick i+1 (4 registers), in flight during the stage of brick i
+    //   end of stage i    row bounds of brick i+1 from them, then its point loads (16 registers)
+    auto origin = [&](int brick, int& bx, int& ox, int& oy, int& oz) {
+        bx = brick % nbx;
+        const int by = (brick / nbx) % nby, bz = brick / (nbx * nby);
+        ox = bx * BX - 1;
+        oy = by * 2 - 1;
+        oz = bz * 2 - 1;
+    };
+    // cell_start at the column clamped to the grid: column 0 is the row's first index in the sorted array, column HX
+    // its one-past-last, and neighbours differ by a cell's count
+    auto load_cells = [&](int brick, int (&vv)[4]) {
+        int bx, ox, oy, oz;
+        origin(brick, bx, ox, oy, oz);
+        const int gx_lo = ox < 0 ? 0 : ox, gx_hi = (ox + HX - 1) < g.n[0] - 1 ? (ox + HX - 1) : g.n[0] - 1;
+        int gxc = ox + lane;
+        gxc = gxc < gx_lo ? gx_lo : (gxc > gx_hi + 1 ? gx_hi + 1 : gxc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = wave * 4 + j;
+            const int gy = oy + (r & 3), gz = oz + (r >> 2);
+            const bool row_ok = gy >= 0 && gy < g.n[1] && gz >= 0 && gz < g.n[2];
+            // (a row outside the grid reads cell_start[0] = 0 in every column: no points)
+            vv[j] = a.cell_start[row_ok ? (gz * g.n[1] + gy) * g.n[0] + gxc : 0];
+        }
+    };
+    auto load_points = [&](const int (&vv)[4], float4 (&pp)[4]) {
+        const int last = a.n - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gs = __builtin_amdgcn_readfirstlane(vv[j]);
+            const int len = __builtin_amdgcn_readlane(vv[j], HX < 63 ? HX : 63) - gs;
+            const int i = gs + (lane < len ? lane : 0);
+            pp[j] = a.snap[i < last ? i : last];
+        }
+    };
+
+    int brick = xcd * per + lane_blk;
+    int v[4] = {0, 0, 0, 0};
+    float4 pv[4];
+    pv[0] = pv[1] = pv[2] = pv[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (brick < b_end) {
+        load_cells(brick, v);
+        load_points(v, pv);
+    }
+    for (; brick < b_end; brick += blk_per_group) {
+        int bx, ox, oy, oz; // halo origin (cell coordinates)
+        origin(brick, bx, ox, oy, oz);
+        const int next = brick + blk_per_group;
+
+        __syncthreads(); // previous brick's LDS no longer in use
+        int vn[4] = {0, 0, 0, 0};
+        if (next < b_end) load_cells(next, vn);
+        // ---- 1. cell table.  Wave w owns the halo x-rows r = 4w .. 4w+3 (r = hz*4 + hy), lane = column hx.
+        //         The prefix the LDS order (hx, hz, hy) needs — points left of column hx in all rows, plus the
+        //         column's cells in rows before r — is a sum of cell_start values: no scan across lanes. -----
+        int cn[4];
+        int row_gs[4], row_len[4];
+        {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int nxt = __shfl_down(v[j], 1, 64);
+                cn[j] = lane < HX ? nxt - v[j] : 0;
+                row_gs[j] = __builtin_amdgcn_readfirstlane(v[j]);
+                row_len[j] = __builtin_amdgcn_readlane(v[j], HX < 63 ? HX : 63) - row_gs[j];
+            }
+            if (lane <= HX) {
+                sm->wsum[wave][lane] = (uint32_t)(v[0] + v[1] + v[2] + v[3]);
+                sm->wcnt[wave][lane] = (uint32_t)(cn[0] + cn[1] + cn[2] + cn[3]);
+                if (wave == 1 || wave == 2) sm->wown[wave - 1][lane] = (uint32_t)(v[1] + v[2]); // rows 5, 6 / 9, 10
+            }
+            if (lane < HX) {
+                uint4 hv;
+                hv.x = (uint32_t)v[0];
+                hv.y = (uint32_t)v[1];
+                hv.z = (uint32_t)v[2];
+                hv.w = (uint32_t)v[3];
+                *reinterpret_cast<uint4*>(&sm->hglobal[lane * kCsSlab + wave * 4]) = hv;
+            }
+        }
+        __syncthreads();
+        CS_STAMP(0) // cell table
+        int halo_total;
+        {
+            uint32_t left = 0, g0 = 0, before = 0, tot = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                left += sm->wsum[w][lane <= HX ? lane : 0];
+                g0 += sm->wsum[w][0];
+                tot += sm->wsum[w][HX];
+                before += w < wave ? sm->wcnt[w][lane <= HX ? lane : 0] : 0u;
+            }
+            halo_total = (int)(tot - g0);
+            if (lane < HX) {
+                uint32_t e = left - g0 + before, o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[j] = e > 0xFFFFu ? 0xFFFFu : e;
+                    e += (uint32_t)cn[j];
+                }
+                uint2 w2;
+                w2.x = o[0] | (o[1] << 16);
+                w2.y = o[2] | (o[3] << 16);
+                *reinterpret_cast<uint2*>(&sm->ls[lane * kCsSlab + wave * 4]) = w2;
+            }
+            if (tid == 0) sm->ls[ncell] = (uint16_t)(halo_total > 0xFFFF ? 0xFFFF : halo_total);
+            if (tid < kCsThreads / 64) sm->miss_n[tid] = 0;
+            // own queries in front of slab hx (slabs 1 .. BX hold own cells; entry BX closes the table)
+            if (wave == 3 && lane >= 1 && lane <= BX + 1) {
+                const uint32_t q = (sm->wown[0][lane] + sm->wown[1][lane]) - (sm->wown[0][1] + sm->wown[1][1]);
+                sm->qpref[lane - 1] = (uint16_t)(q > 0xFFFFu ? 0xFFFFu : q);
+            }
+        }
+        __syncthreads();
+        CS_STAMP(6) // prefix tables
+        const bool overflow = halo_total > hcap;
+        if (tid >= 1 && tid <= BX) {
+            const int q0 = sm->qpref[tid - 1], q1 = sm->qpref[tid];
+            for (int q = q0; q < q1 && q < kCsMaxQ; ++q) sm->qslab[q] = (uint8_t)tid;
+        }
+        // ---- 2. stage the halo: global rows are contiguous, the LDS order is (hx, hz, hy) ---------------
+        if (!overflow) {
+            auto place = [&](const float4& p, int r, int gidx) {
+                int hx = cell_coord(g, p.x, 0) - ox;
+                hx = hx < 0 ? 0 : (hx > HX - 1 ? HX - 1 : hx);
+                const int P = hx * kCsSlab + r;
+                int dest = (int)sm->ls[P] + (gidx - (int)sm->hglobal[P]);
+                dest = dest < 0 ? 0 : (dest > hcap - 1 ? hcap - 1 : dest); // never outside the point area
+                pts[dest] = p;
+            };
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (lane < row_len[j]) place(pv[j], wave * 4 + j, row_gs[j] + lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) // rows longer than a wave: the rest, row by row
+                for (int i = lane + 64; i < row_len[j]; i += 64) place(a.snap[row_gs[j] + i], wave * 4 + j, row_gs[j] + i);
+            // one scan step past the staged points: far sentinels instead of another brick's leftovers
+            // (a run's last step reads up to 7 slots past its end; every CELL past a run is two cells
+            // away from the query, so only the slots past the last cell need this)
+            if (tid < kCsSU) pts[halo_total + tid] = make_float4(1e30f, 1e30f, 1e30f, 0.f);
+        }
+        // the next brick: its cell table has arrived by now, its points fly while this brick's queries run
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = vn[j];
+        if (next < b_end) load_points(v, pv);
+        __syncthreads();
+
+        CS_STAMP(7) // own table, staging
+        if (WTP_DIAG) dt[8] += 1; // bricks (per wave)
+        // ---- 4. queries ------------------------------------------------------------------------------
+#ifdef CS_ABL_NOQUERY // timing-only ablation (results wrong): the stage alone
+        const int Q = 0;
+#else
+        const int Q = sm->qpref[BX];
+#endif
+        if (overflow || Q > kCsMaxQ) {
+            // dense brick (halo larger than the LDS point area, or more queries than the lane table holds):
+            // every own point goes to the exact path.  Own points = four x-rows of the sorted array.
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int gy = oy + 1 + (r4 & 1), gz = oz + 1 + (r4 >> 1);
+                if (gy >= g.n[1] || gz >= g.n[2]) continue;
+                const int gx0 = bx * BX, gx1 = (gx0 + BX - 1) < g.n[0] - 1 ? (gx0 + BX - 1) : g.n[0] - 1;
+                const int base = (gz * g.n[1] + gy) * g.n[0];
+                const int s = a.cell_start[base + gx0], e = a.cell_start[base + gx1 + 1];
+                for (int i = s + tid; i < e; i += kCsThreads) {
+                    const int pos = atomicAdd(a.fb_count, 1);
+                    a.fb_list[pos] = i;
+                }
+            }
+            continue;
+        }
+        for (int qb = 0; qb < Q; qb += kCsThreads) {
+            const int q = qb + tid;
+            const bool active = q < Q;
+            // lane table -> (slab, own cell, slot)
+            int hx = 1, cellp = 5, slot = 0, gslot = 0;
+            if (active) {
+                hx = sm->qslab[q];
+                const int off = q - (int)sm->qpref[hx - 1];
+                const int b = hx * kCsSlab;
+                const int s5 = sm->ls[b + 5], s6 = sm->ls[b + 6], s7 = sm->ls[b + 7];
+                const int s9 = sm->ls[b + 9], s10 = sm->ls[b + 10];
+                const int n56 = s7 - s5;
+                if (off < n56) {
+                    slot = s5 + off;
+                    cellp = slot < s6 ? 5 : 6;
+                } else {
+                    slot = s9 + (off - n56);
+                    cellp = slot < s10 ? 9 : 10;
+                }
+                gslot = (int)sm->hglobal[b + cellp] + (slot - (int)sm->ls[b + cellp]);
+            }
+            if (!active) continue;
+            const uint32_t qoff = (uint32_t)slot * 16u;
+            const float4 qp = pts[slot];
+            const int32_t qid = w_to_id(qp.w);
+            if (qid < a.n_fixed) { // the wall: never moves (src/repel.jl:80,256)
+                a.out[gslot] = qp;
+                a.forces[gslot] = 0.f;
+                a.nn_dist[gslot] = Lim<float>::inf();
+                a.nn_id[gslot] = -1;
+                continue;
+            }
+            const int hy = cellp & 3, hz = cellp >> 2;
+            const int cx = ox + hx, cy = oy + hy, cz = oz + hz;
+            float s = s_c, inv_s2 = inv_s2_c, lim = lim_c;
+            // the support must lie inside the radius up to which the 27 cells are provably complete.  With a
+            // constant spacing and cells sized for it that holds for every query (the radius is at least
+            // c - margin): checked once per kernel, and the radius is worked out for the few misses only.
+            bool cs_fail = false;
+            if (!const_ok) { // wave-uniform
+                if (a.spacing_pp) {
+                    s = a.spacing_pp[qid];
+                    inv_s2 = 1.f / (s * s);
+                    lim = (a.u0 * a.u0) * (s * s);
+                }
+                cs_fail = !(lim <= safe_radius2(g, qp.x, qp.y, qp.z, cx, cy, cz, 1));
+            }
+            // candidate run: halo cells P(hx-1, hz-1, hy-1) .. P(hx+1, hz+1, hy+1), contiguous in LDS
+            const int Pf = (hx - 1) * kCsSlab + (hz - 1) * 4 + (hy - 1);
+            const uint32_t pa0 = (uint32_t)sm->ls[Pf] * 16u, ea = (uint32_t)sm->ls[Pf + kCsRun] * 16u;
+            // ring: one byte per hit = slot index inside the run; runs beyond 255 slots (dense cluster) give up
+            bool giveup = (ea - pa0) > 255u * 16u;
+            float tau_s = (cs_fail || giveup) ? -1.f : lim * (1.f + 0x1p-21f); // FMA filter, 4 ulp wide; the ring pass is exact
+            const uint32_t ring_b = ring_off + (uint32_t)tid * (uint32_t)kCsRingStride;
+            uint32_t ra = ring_b; // next free ring byte (the running address itself: one add-with-carry per candidate)
+            const uint32_t lds_base = (uint32_t)(uintptr_t)smem_raw;
+            CS_STAMP(1) // query setup
+            if (WTP_DIAG) {
+                dt[9] += 1;                                           // query rounds (per wave)
+                dt[10] += (unsigned long long)__popcll(__ballot(true)); // queries
+            }
+            uint32_t idx0 = 0; // slot index of the step's first candidate inside the run
+            for (uint32_t pa = pa0; __any(pa < ea); pa += 16u * kCsSU, idx0 += kCsSU) {
+                if (WTP_DIAG) {
+                    dt[11] += 1; // scan steps (per wave)
+                    dt[12] += (unsigned long long)__popcll(__ballot(pa < ea)); // busy lanes
+                }
+                if (__any(ra > ring_b + (uint32_t)kCsRing)) { // a lane's ring is full (dense cluster): that lane gives up
+                    if (ra > ring_b + (uint32_t)kCsRing) {
+                        giveup = true;
+                        ra = ring_b;
+                        tau_s = -1.f;
+                    }
+                }
+                // a lane whose run has ended keeps reading its first slots with an impossible threshold.  Inside a
+                // run no end mask is needed: the slots a last step reads past the run's end belong to cells two
+                // away from the query (or are the sentinels behind the last cell) and fail the distance test.
+                const bool busy = pa < ea;
+                const float thr = busy ? tau_s : -1.f;
+                const uint32_t addr = lds_base + (busy ? pa : pa0);
+                cs_f4 c[4]; // two half steps: 16 registers of candidates instead of 32 (the next brick's loads sit in registers too)
+                cs_read_group<0>(c, addr);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float ex = qp.x - c[u].x, ey = qp.y - c[u].y, ez = qp.z - c[u].z;
+                    const float d = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
+                    smem_raw[ra] = (unsigned char)(idx0 + u); // unconditional: rewritten or never read
+                    ra += (d <= thr) ? 1u : 0u;
+                }
+                cs_read_group<64>(c, addr);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float ex = qp.x - c[u].x, ey = qp.y - c[u].y, ez = qp.z - c[u].z;
+                    const float d = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
+                    smem_raw[ra] = (unsigned char)(idx0 + 4 + u);
+                    ra += (d <= thr) ? 1u : 0u;
+                }
+            }
+            const uint32_t cnt = ra - ring_b;
+            CS_STAMP(2) // scan
+
+            // ---- ring pass: canonical d2 of every survivor, exact cut, force sum (src/repel.jl:270-280) ----
+            const ForceCoefCs fc = force_coef_cs(a.beta, a.u0);
+            int n_lim = 0;
+            bool coincident = false;
+            float Fx = 0.f, Fy = 0.f, Fz = 0.f;
+            int32_t nid = 0x7FFFFFFF;
+            float nd2 = Lim<float>::inf();
+            for (uint32_t j0 = 0; __any(j0 < cnt); j0 += 4) {
+                if (WTP_DIAG) dt[13] += 1; // ring batches (per wave)
+                const uint32_t e4 = *reinterpret_cast<const uint32_t*>(smem_raw + ring_b + j0); // four entries
+                float4 c[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t e = (j0 + u) < cnt ? ((e4 >> (8 * u)) & 0xFFu) : 0u;
+                    c[u] = cs_pt(smem_raw, pa0 + e * 16u);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float dx = qp.x - c[u].x, dy = qp.y - c[u].y, dz = qp.z - c[u].z;
+                    const float d = (dx * dx + dy * dy) + dz * dz;
+                    const int32_t cid = w_to_id(c[u].w);
+                    const bool inl = ((j0 + u) < cnt) && (d <= lim);
+                    n_lim += inl ? 1 : 0;
+                    const bool act = inl && (cid != qid); // self skipped by index (src/repel.jl:271)
+                    const bool nearer = act && lex_lt(d, cid, nd2, nid);
+                    nd2 = nearer ? d : nd2;
+                    nid = nearer ? cid : nid;
+                    const float f = force_fast_cs(fc, d * inv_s2);
+                    const float coef = (act && d > 0.f) ? f * __builtin_amdgcn_rsqf(d) : 0.f;
+                    Fx = __builtin_fmaf(coef, dx, Fx); // (this path's sum order differs from the reference's anyway)
+                    Fy = __builtin_fmaf(coef, dy, Fy);
+                    Fz = __builtin_fmaf(coef, dz, Fz);
+                    coincident = coincident || (act && !(d > 0.f));
+                }
+            }
+            CS_STAMP(3) // ring pass
+            // not provable here: support wider than the certified radius, ring overflow, more than k points
+            // inside the support (then some of them are NOT among the k nearest), r = 0 (substitute direction)
+            if (cs_fail || giveup || n_lim > K || coincident) {
+                const int pos = atomicAdd(a.fb_count, 1);
+                a.fb_list[pos] = gslot;
+                continue;
+            }
+            float4 o;
+            const float f = step_point<float>(a, s, qp.x, qp.y, qp.z, Fx, Fy, Fz, o.x, o.y, o.z);
+            o.w = qp.w;
+            a.out[gslot] = o;
+            a.forces[gslot] = f;
+            const bool has = nid != 0x7FFFFFFF;
+            if (has) {
+                // the nearest point of the support is the nearest overall: everything outside is farther
+                const float nd = wsqrt(nd2);
+                if (reaches_past_cover<float>(a, qp.x, qp.y, qp.z, lim)) atomicAdd(a.uncovered, 1);
+                a.nn_dist[gslot] = nd;
+                a.nn_id[gslot] = nid;
+                cs_acc_point(acc, f, nd, s, qid, nid);
+            }
+            // empty support: the wave looks for the nearest neighbour afterwards (deterministic order:
+            // position = rank of the lane among this round's misses)
+            const unsigned long long mm = __ballot(!has);
+            if (mm) {
+                const int base_m = sm->miss_n[wave];
+                if (!has) {
+                    const int pos = base_m + (int)__popcll(mm & ((1ull << lane) - 1ull));
+                    if (pos < kCsMiss) {
+                        CsMiss e;
+                        e.pa = pa0;
+                        e.ea = ea;
+                        e.qoff = qoff;
+                        e.gslot = gslot;
+                        e.qid = qid;
+                        e.f = f;
+                        e.s = s;
+                        e.g2 = safe_radius2(g, qp.x, qp.y, qp.z, cx, cy, cz, 1);
+                        sm->miss[wave][pos] = e;
+                    } else { // list full: exact path (it recomputes the whole query)
+                        const int p2 = atomicAdd(a.fb_count, 1);
+                        a.fb_list[p2] = gslot;
+                    }
+                }
+                // one lane updates the count after every lane has read it
+                const int first = __ffsll((long long)mm) - 1;
+                const int tot = base_m + (int)__popcll(mm);
+                __builtin_amdgcn_wave_barrier();
+                if (lane == first) sm->miss_n[wave] = tot < kCsMiss ? tot : kCsMiss;
+                __builtin_amdgcn_wave_barrier();
+            }
+            CS_STAMP(4) // step, outputs, statistics
+        }
+
+        // ---- 5. empty-support queries of this wave: cooperative nearest-neighbour search in the run ----------
+        {
+            const int nm = __builtin_amdgcn_readfirstlane(sm->miss_n[wave]);
+            for (int m = 0; m < nm; ++m) {
+                const CsMiss e = sm->miss[wave][m];
+                const float4 qp = cs_pt(smem_raw, e.qoff);
+                float bd = Lim<float>::inf();
+                int32_t bi = 0x7FFFFFFF;
+                for (uint32_t p = e.pa + (uint32_t)lane * 16u; p < e.ea; p += 64u * 16u) {
+                    const float4 c = cs_pt(smem_raw, p);
+                    const int32_t cid = w_to_id(c.w);
+                    const float d = dist2<float>(qp.x, qp.y, qp.z, c.x, c.y, c.z);
+                    if (cid != e.qid && lex_lt(d, cid, bd, bi)) {
+                        bd = d;
+                        bi = cid;
+                    }
+                }
+#pragma unroll
+                for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+                    const float od = __shfl_xor(bd, dlt, 64);
+                    const int32_t oi = __shfl_xor(bi, dlt, 64);
+                    if (lex_lt(od, oi, bd, bi)) {
+                        bd = od;
+                        bi = oi;
+                    }
+                }
+                if (lane == 0) {
+                    // certified when the winner lies inside the radius up to which the 27 cells are complete
+                    // (the run's extra cells only add points beyond it)
+                    if (bi != 0x7FFFFFFF && bd <= e.g2) {
+                        const float nd = wsqrt(bd);
+                        if (reaches_past_cover<float>(a, qp.x, qp.y, qp.z, bd)) atomicAdd(a.uncovered, 1);
+                        a.nn_dist[e.gslot] = nd;
+                        a.nn_id[e.gslot] = bi;
+                        cs_acc_point(acc, e.f, nd, e.s, e.qid, bi);
+                    } else { // not certified by the 27 cells: the follow-up kernel searches 5 x 5 x 5
+                        const int pos = atomicAdd(a.nn_count, 1);
+                        a.nn_list[pos] = e.gslot;
+                    }
+                }
+            }
+            if (WTP_DIAG) dt[14] += (unsigned long long)nm;
+        }
+        CS_STAMP(5) // empty-support follow-up
+    }
+    if (WTP_DIAG && lane == 0) {
+        for (int i = 0; i < 15; ++i) atomicAdd(&a.diag[i], dt[i]);
+        atomicAdd(&a.diag[15], 1ull);
+    }
+    __syncthreads();
+    Acc full = acc_empty();
+    full.max_force = (double)acc.max_force;
+    full.sum_u = acc.sum_u;
+    full.sum_u2 = acc.sum_u2;
+    full.n_move = acc.n_move;
+    if (acc.argmin_i >= 0) {
+        full.argmin_r = (double)acc.argmin_r;
+        full.argmin_i = acc.argmin_i;
+        full.argmin_j = acc.argmin_j;
+    }
+    acc_block_reduce(full, sm->acc);
+    if (tid == 0) acc_store(&a.partials[blockIdx.x], full);
+}
+
+// Brick census (once per session): own points Q and halo points H of every brick for a candidate BX,
+// as histograms (Q in bins of 2, H in bins of 8), so the host can size BX and the LDS point area
+// from what the bricks of THIS cloud hold instead of from a density model.
+__global__ void cs2_census_kernel(const int32_t* __restrict__ cell_start, const Grid<float>* __restrict__ gp, int BX,
+                                  unsigned int* __restrict__ out /* [256 Q-bins | 256 H-bins | non-empty bricks] */) {
+    const Grid<float> g = *gp;
+    const int nbx = (g.n[0] + BX - 1) / BX, nby = (g.n[1] + 1) / 2, nbz = (g.n[2] + 1) / 2;
+    const int nbricks = nbx * nby * nbz;
+    for (int brick = blockIdx.x * blockDim.x + threadIdx.x; brick < nbricks; brick += gridDim.x * blockDim.x) {
+        const int bx = brick % nbx, by = (brick / nbx) % nby, bz = brick / (nbx * nby);
+        const int gx0 = bx * BX, gx1 = (gx0 + BX - 1) < g.n[0] - 1 ? (gx0 + BX - 1) : g.n[0] - 1;
+        const int hx0 = gx0 > 0 ? gx0 - 1 : 0, hx1 = gx1 + 1 < g.n[0] - 1 ? gx1 + 1 : g.n[0] - 1;
+        int Q = 0, H = 0;
+        for (int r = 0; r < 16; ++r) {
+            const int gy = by * 2 - 1 + (r & 3), gz = bz * 2 - 1 + (r >> 2);
+            if (gy < 0 || gy >= g.n[1] || gz < 0 || gz >= g.n[2]) continue;
+            const int base = (gz * g.n[1] + gy) * g.n[0];
+            H += cell_start[base + hx1 + 1] - cell_start[base + hx0];
+            const bool own = ((r & 3) == 1 || (r & 3) == 2) && ((r >> 2) == 1 || (r >> 2) == 2);
+            if (own) Q += cell_start[base + gx1 + 1] - cell_start[base + gx0];
+        }
+        if (Q == 0) continue;
+        atomicAdd(&out[Q / 2 < 255 ? Q / 2 : 255], 1u);
+        atomicAdd(&out[256 + (H / 8 < 255 ? H / 8 : 255)], 1u);
+        atomicAdd(&out[512], 1u);
+    }
+}
+
+int launch_cs2_census(wtp_ctx* ctx, int BX, unsigned int* d_out513) {
+    WTP_HIP(ctx, hipMemsetAsync(d_out513, 0, 513 * sizeof(unsigned int), ctx->stream));
+    hipLaunchKernelGGL(cs2_census_kernel, dim3(512), dim3(256), 0, ctx->stream, (const int32_t*)ctx->cell_start.p,
+                       (const Grid<float>*)ctx->grid.p, BX, d_out513);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
+int cs2_max_bx() { return kCsMaxBX; }
+
+// Follow-up of cs2_kernel: the queries whose nearest neighbour the 27 staged cells could not certify
+// (empty support AND the winner beyond the provable radius: ~0.5 % of a uniform cloud).  Force, step and
+// new position are final already; what is missing is nn_dist / nn_id and the point's share of the
+// statistics.  One lane per query, 5 x 5 x 5 cells straight from the sorted array (25 contiguous runs),
+// canonical (d2, id) minimum, certified against the radius the 125 cells cover; whatever is left (isolated
+// points) goes to the exact path, which recomputes the whole query.
+constexpr int kNnFixBlocks = 256;
+constexpr int kNnFixThreads = 1024; // 16 waves per block, one query per wave at a time: the search is a chain of
+                                    // dependent global loads, so it wants many waves in flight, not many lanes per query
+__global__ __launch_bounds__(kNnFixThreads) void cs2_nnfix_kernel(SearchArgs<float> a, int part_base) {
+    __shared__ Acc sacc[kNnFixThreads / 64];
+    const Grid<float> g = *a.grid;
+    const int n = *a.nn_count;
+    const int lane = threadIdx.x & 63;
+    const int wave_g = (blockIdx.x * kNnFixThreads + threadIdx.x) >> 6, nwaves = (gridDim.x * kNnFixThreads) >> 6;
+    Acc acc = acc_empty();
+    // four queries per wave, 16 lanes each: lane l of a group takes the rows l and l + 16 of the 25 (dz, dy) rows
+    const int grp = lane >> 4, l16 = lane & 15;
+    for (int i0 = wave_g * 4; i0 < n; i0 += nwaves * 4) {
+        const int i = i0 + grp;
+        const bool on = i < n;
+        const int gslot = a.nn_list[on ? i : i0];
+        const float4 qp = a.snap[gslot];
+        const int32_t qid = w_to_id(qp.w);
+        const int cx = cell_coord(g, qp.x, 0), cy = cell_coord(g, qp.y, 1), cz = cell_coord(g, qp.z, 2);
+        float bd = Lim<float>::inf();
+        int32_t bi = 0x7FFFFFFF;
+        const int x0 = cx - 2 < 0 ? 0 : cx - 2, x1 = cx + 2 > g.n[0] - 1 ? g.n[0] - 1 : cx + 2;
+        int p0[2], p1[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { // both rows' bounds in flight together
+            const int r = l16 + 16 * t;
+            const int gz = cz + r / 5 - 2, gy = cy + r % 5 - 2;
+            const bool ok = r < 25 && gz >= 0 && gz < g.n[2] && gy >= 0 && gy < g.n[1];
+            const int base = ok ? (gz * g.n[1] + gy) * g.n[0] : 0;
+            p0[t] = a.cell_start[base + x0];
+            p1[t] = ok ? a.cell_start[base + x1 + 1] : p0[t];
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            for (int p = p0[t]; p < p1[t]; ++p) {
+                const float4 c = a.snap[p];
+                const int32_t cid = w_to_id(c.w);
+                const float d = dist2<float>(qp.x, qp.y, qp.z, c.x, c.y, c.z);
+                if (cid != qid && lex_lt(d, cid, bd, bi)) {
+                    bd = d;
+                    bi = cid;
+                }
+            }
+#pragma unroll
+        for (int dlt = 8; dlt >= 1; dlt >>= 1) { // minimum over the group's 16 lanes
+            const float od = __shfl_xor(bd, dlt, 64);
+            const int32_t oi = __shfl_xor(bi, dlt, 64);
+            if (lex_lt(od, oi, bd, bi)) {
+                bd = od;
+                bi = oi;
+            }
+        }
+        if (l16 == 0 && on) {
+            const float g2 = safe_radius2(g, qp.x, qp.y, qp.z, cx, cy, cz, 2);
+            if (bi != 0x7FFFFFFF && bd <= g2) {
+                const float s = a.spacing_pp ? a.spacing_pp[qid] : a.spacing_const;
+                const float nd = wsqrt(bd);
+                if (reaches_past_cover<float>(a, qp.x, qp.y, qp.z, bd)) atomicAdd(a.uncovered, 1);
+                a.nn_dist[gslot] = nd;
+                a.nn_id[gslot] = bi;
+                acc_point<float>(acc, a.forces[gslot], nd, s, qid, bi);
+            } else {
+                const int pos = atomicAdd(a.fb_count, 1);
+                a.fb_list[pos] = gslot;
+            }
+        }
+    }
+    acc_block_reduce(acc, sacc);
+    if (threadIdx.x == 0) acc_store(&a.partials[part_base + blockIdx.x], acc);
+}
+
+int launch_cs2(wtp_ctx* ctx, SearchArgs<float>& a) {
+    const int hcap = a.brick_hcap, BX = a.cs2_bx;
+    if (hcap < 64 || hcap > 4096 || BX < 1 || BX > kCsMaxBX)
+        return fail(ctx, WTP_ERR_STATE, "compact-support sweep launched without a brick geometry");
+    const size_t smem = cs2_smem_bytes(hcap);
+    if (ctx->cs2_smem != smem) { // per context: several contexts (devices) may coexist in one process
+        WTP_HIP(ctx, hipFuncSetAttribute((const void*)cs2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        int occ = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cs2_kernel, kCsThreads, smem);
+        if (e != hipSuccess || occ < 1) occ = 1;
+        ctx->cs2_occ = occ > 4 ? 4 : occ;
+        ctx->cs2_smem = smem;
+    }
+    int gsz = ctx->sm_count * ctx->cs2_occ;
+    gsz -= gsz % 8;
+    if (gsz < 8) gsz = 8;
+    hipLaunchKernelGGL(cs2_kernel, dim3(gsz), dim3(kCsThreads), smem, ctx->stream, a, hcap, BX);
+    // its partial slots follow the bricks' (brick_partials() leaves room for them)
+    hipLaunchKernelGGL(cs2_nnfix_kernel, dim3(kNnFixBlocks), dim3(kNnFixThreads), 0, ctx->stream, a, gsz);
+    a.used_brick = gsz + kNnFixBlocks;
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
+} // namespace wtp

@@ -116,6 +116,8 @@ template <typename T> struct SearchArgs {
     int32_t* fb_count;
     int32_t* fb2_list;         // second level: wave kernel -> serial kernel
     int32_t* fb2_count;
+    int32_t* nn_list;          // round-2 sweep: queries whose nearest neighbour the follow-up kernel still has to find
+    int32_t* nn_count;
     // sharded sessions: the snapshot is complete only for cover_lo <= coord[cover_axis] <= cover_hi;
     // queries whose neighbourhood reaches past that range are counted (wtp_relax_set_coverage)
     int32_t cover_axis;        // -1: unlimited
@@ -125,6 +127,7 @@ template <typename T> struct SearchArgs {
     T gamma_cap;               // initial filter radius cap, in cell edges
     T tnn_frac;                // CS sweeps: nearest-neighbour margin of the ring, in cell edges (WTP_TNN, default 0.8)
     int32_t brick_hcap;        // LDS point capacity for the brick kernel (0 = default)
+    int32_t cs2_bx;            // > 0: brick length (own cells along x) of the round-2 compact-support sweep (wtp_cs2.hip)
     unsigned long long* diag;  // -DWTP_DIAG builds: per-phase wave-cycle sums (8 slots), else unused
 };
 
@@ -167,6 +170,8 @@ struct RelaxState {
     double spacing_typ = 0;  // mean spacing over the snapshot (floor of the compact-support cell edge)
     bool cs_sweep = false;   // compact-support sweep in use (ClippedSpacingForce)
     bool cs_disabled = false; // measured on the first rebuild: support cells would be over-full, use the k-selection sweep
+    int cs2_bx = 0;          // > 0: the round-2 compact-support sweep (wtp_cs2.hip) with bricks of this many cells along x
+    int64_t tuned_fixed = 0; // fixed points the grid / brick geometry was measured with (a swapped head re-measures when it differs by > 5 % of n)
     double sp_p0 = 0, sp_p1 = 0, sp_p2 = 0; // LOGLIKE / BOUNDARY_LAYER parameters
     HashView pending;        // wtp_relax_set_fixed_dev left its work to the next rebuild (see there)
     int64_t shard_extra = 0; // extra capacity of the point buffers once the fixed head gets replaced
@@ -191,6 +196,10 @@ struct wtp_ctx {
     double tnn_frac = 0.8;     // WTP_TNN: measured optimum between candidate volume and isolated-query hand-backs (0.9: 1.55 ms, 0.8: 1.44, 0.7: 1.69 per 10 M step)
     int force_generic = 0;
     int full_select = 0;       // WTP_FULL_SELECT=1: never use the compact-support sweep
+    int cs2 = 1;               // WTP_CS2=0: the round-1 compact-support sweep (brick_kernel<1,0,1>) instead of wtp_cs2.hip
+    double rho_cs2 = 1.0;      // WTP_RHO_CS: target points per cell of the round-2 sweep (the support floor usually binds)
+    size_t cs2_smem = 0;       // launch attributes of cs2_kernel cached per context
+    int cs2_occ = 0;
     double styp_sigma = 0.0;   // WTP_STYP_SIGMA: typical spacing = mean + this many standard deviations (measured: > 0 only hurts)
     int64_t knn_tune_n = -1;   // topology calls: cloud size / dim / k the cached cell scale was measured for
     int knn_tune_dim = 0, knn_tune_k = 0;
@@ -210,7 +219,7 @@ struct wtp_ctx {
     wtp::DevBuf idx_out, dist_out, counts_out;
     wtp::DevBuf cand_idx, cand_dist, f32_pts; // fp64 topology: fp32 candidate lists and the float copy of the cloud
     wtp::DevBuf forces, nn_dist, nn_id, spacing_pp;
-    wtp::DevBuf partials, stats, fb_list, fb_count, fb2_list, fb2_count;
+    wtp::DevBuf partials, stats, fb_list, fb_count, fb2_list, fb2_count, nn_list;
     wtp::DevBuf scratch;       // misc (relax_get staging, radius rows)
     wtp::DevBuf diag;          // diagnostic builds only
     wtp::DevBuf ins_in, ins_elems, ins_partial, ins_out; // isinside filter
@@ -308,6 +317,10 @@ template <typename T> int launch_query_knn(wtp_ctx* ctx, SearchArgs<T>& a, const
 template <typename T> int launch_generic_sweep(wtp_ctx* ctx, SearchArgs<T>& a, bool all);
 inline int total_partials() { return brick_partials() + kWavePartials + kGenericPartials; }
 int launch_brick_radius(wtp_ctx* ctx, SearchArgs<float>& a);
+// round-2 compact-support sweep (wtp_cs2.hip)
+int launch_cs2(wtp_ctx* ctx, SearchArgs<float>& a);
+int launch_cs2_census(wtp_ctx* ctx, int BX, unsigned int* d_out513);
+int cs2_max_bx();
 template <typename T>
 int launch_radius_count(wtp_ctx* ctx, SearchArgs<T>& a, T r, int32_t* d_counts);
 template <typename T>
