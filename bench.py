@@ -8,9 +8,11 @@ the achieved fraction of the HBM roofline of the dominant kernel next to it.
     python bench.py [--gpus N] [--steps K] [--warmup W] [--points P] [--no-cpu]
 
 One step = one pass of the hot path (src/repel.jl:244-293) over the whole cloud, coordinates
-resident in HBM.  N > 1 is launched by torch.distributed.run, one rank per GPU; the cloud is
-sharded into z-slabs with a one-cell ghost layer exchanged through RCCL every iteration
-(whatsthepoint.jl_amd/sharded.py).  Rank 0 prints ONE JSON line.
+resident in HBM.  N > 1: one rank per GPU — either under torch.distributed.run, or, when WORLD_SIZE is not
+set, this script starts its N ranks itself (child processes, before anything touches a GPU).  The N > 1
+workload is BASELINE.json's configs[3]: 100 M points IN TOTAL (strong scaling: `--total-points`), sharded
+into slabs with a ghost layer exchanged through RCCL every iteration (whatsthepoint.jl_amd/sharded.py).
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -67,8 +69,10 @@ def cpu_baseline(points: int, iters: int):
     O.relax_loop(x, 0, s, 2, 0.2, 1.0, 3.0, 21, s / 2000, s / 20, max_iters=iters, tol=0.0, rebuild_every=1,
                  stall_after=0)
     dt = time.perf_counter() - t0
+    kd = O.kd_build_seconds(x)  # the serial part of every iteration (like KDTree(coords), src/repel.jl:252)
     return dict(value=points * iters / dt / 1e6, unit="Mpoints/s", cores=O.num_threads(), kind="port",
-                sample=f"{iters} repel iterations on {points} uniform fp32 points (kd-tree + OpenMP oracle, {dt:.1f} s)")
+                sample=f"{iters} repel iterations on {points} uniform fp32 points (kd-tree + OpenMP oracle, {dt:.1f} s)",
+                kd_build_share=round(kd * iters / dt, 3), kd_build_s=round(kd, 3))
 
 
 def cube_mesh(np, m):
@@ -100,7 +104,7 @@ def cube_mesh(np, m):
     return np.array(verts, dtype=np.float32), np.array(tris, dtype=np.int32)
 
 
-def other_paths(ctx, torch, np, wtp_amd, extra_legs=False):
+def other_paths(ctx, torch, np, wtp_amd, extra_legs=False, e2e=True):
     """Secondary lines of SURVEY.md §8d, measured in the same run on the same GPU (N=1 only):
     KNNTopology k=21 at 1 M points (C2), RadiusTopology on 1 M points at a radius holding ~21
     neighbours, and the isinside filter of repel's tail.  Device-resident where the ABI allows."""
@@ -176,11 +180,12 @@ def other_paths(ctx, torch, np, wtp_amd, extra_legs=False):
         "value": round(len(t) / dt / 1e6, 2), "unit": "Mpoints/s", "ms": round(dt * 1e3, 2), "kernel_ms": round(dev * 1e3, 2),
         "inside_fraction": round(float(ins2.mean()), 4), "agrees_with_greens": round(float((ins2 == ins).mean()), 5),
         "note": "wtp_mesh_query (bounding-volume tree, per-lane stackless walk), host arrays in and out, unsorted queries"}
-    if not extra_legs:
-        # The legs below launch the headline's own kernel (brick_kernel<1,0,1>) on other workloads; they are
-        # opt-in (--extra-legs) so that a rocprofv3 --stats summary of the default command averages that
-        # kernel over the headline's launches only.  profiles/ holds a run with them.
+    if not e2e:
         return out
+    # The legs below launch the headline's own kernel on other workloads.  They are part of the default run
+    # (config 3 reads max_iters = 1000; "uniform and graded clouds" is the north star's wording); the headline's
+    # roofline figure is taken from HIP events around the timed region only, and tools/profile_round.sh passes
+    # --no-e2e where a rocprofv3 --stats average over the headline's launches alone is wanted.
     # end to end: 1000 repel iterations on 10 M points, host array in -> host array out
     # (PCIe both ways, session setup, all iterations, read-back), no stop rule firing (tol = 0)
     ne = 10_000_000
@@ -195,6 +200,13 @@ def other_paths(ctx, torch, np, wtp_amd, extra_legs=False):
                                               "final_max_force": float(conv[-1]), "moved": bool(np.abs(pe - xe).max() > 0),
                                               "note": "host array in, 1000 iterations (rebuild every step), host array out"}
     del xe, pe
+    if extra_legs:
+        _octree_leg(out, ctx, np, wtp_amd, mv, mt, oc, time)
+    _graded_legs(out, ctx, np, wtp_amd, time)
+    return out
+
+
+def _octree_leg(out, ctx, np, wtp_amd, mv, mt, oc, time):
     # the octree method (src/repel.jl:122-181): every point moves, wall rule on 46 128 triangles after each sweep
     cen = mv[mt].mean(axis=1).astype(np.float32)
     no_ = 10_000_000
@@ -215,6 +227,9 @@ def other_paths(ctx, torch, np, wtp_amd, extra_legs=False):
         "note": "boundary points re-projected onto the mesh, volume points tested against it, every iteration "
                 "(wall_rule_ms includes the step's reductions, ~0.2 ms)"}
     del xo
+
+
+def _graded_legs(out, ctx, np, wtp_amd, time):
     # graded cloud (BASELINE config 5 / north star "uniform and graded clouds"): thinned uniform stream,
     # h_bulk/h_wall = 4, with its own BoundaryLayerSpacing law evaluated on the device
     ng = 1_000_000
@@ -253,7 +268,36 @@ def other_paths(ctx, torch, np, wtp_amd, extra_legs=False):
     out["graded_radius_topology_1M"] = {"value": round(ng / dt / 1e6, 1), "unit": "Mpoints/s", "ms": round(dt * 1e3, 2),
                                         "kernel_ms": round(tm["hash_ms"] + tm["sweep_ms"] + tm["other_ms"], 3),
                                         "pairs": int(off[-1]), "note": "r = 2.5 h_wall, host arrays in and out"}
-    return out
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes of a parent that never
+    touches a GPU, relay rank 0's JSON line (the children inherit stdout), return the worst exit code.  With fewer
+    visible GPUs than ranks the ranks share GPU 0 over gloo (rehearsal of the N > 1 path on a one-GPU box)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env0 = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if "WTP_BENCH_REHEARSAL" not in env0:
+        try:
+            import torch  # device_count() does not initialise the GPU on this image
+
+            if torch.cuda.device_count() < n:
+                env0["WTP_BENCH_REHEARSAL"] = "1"
+        except Exception:
+            pass
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, pr.wait())
+    return rc
 
 
 def ctx_rho() -> float:
@@ -268,15 +312,34 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--points", type=int, default=10_000_000, help="points per GPU (weak scaling)")
+    ap.add_argument("--points", type=int, default=10_000_000, help="points on ONE GPU (the N = 1 workload, configs[2])")
+    ap.add_argument("--total-points", type=int, default=0,
+                    help="N > 1: points in total, split over the ranks (default 100 M = configs[3]; strong scaling)")
+    ap.add_argument("--weak", action="store_true", help="N > 1: --points per GPU instead of a fixed total")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-full-select", action="store_true", help="skip the explicit k-selection leg")
     ap.add_argument("--no-other-paths", action="store_true", help="skip the k-NN / radius / isinside lines")
-    ap.add_argument("--extra-legs", action="store_true",
-                    help="also: 1000-iteration end-to-end repel at 10 M points, graded-cloud repel and radius lines")
+    ap.add_argument("--extra-legs", action="store_true", help="also: the octree-method leg (wall rule on a 46 k-triangle mesh)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the 1000-iteration end-to-end leg and the graded-cloud legs")
     ap.add_argument("--cpu-points", type=int, default=4_000_000)
     ap.add_argument("--cpu-iters", type=int, default=6)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))  # nothing has touched a GPU yet
+
+    # the CPU oracle is built / loaded (a compiler run when the shipped .so looks stale) BEFORE the GPU is
+    # initialised: no child processes from a GPU-initialised process
+    oracle_ready = False
+    if not args.no_cpu and int(os.environ.get("RANK", "0")) == 0:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle as _O
+
+            _O.lib()
+            oracle_ready = True
+        except Exception as e:
+            print(f"[bench] oracle not available: {e}", file=sys.stderr)
 
     import numpy as np
     import torch
@@ -303,8 +366,14 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    n_local = args.points
-    n_total = n_local * world
+    if world == 1:
+        n_total = n_local = args.points
+        scaling = "weak"  # (one GPU: the label is moot)
+    elif args.weak:
+        n_local, n_total, scaling = args.points, args.points * world, "weak"
+    else:
+        n_total = args.total_points or 100_000_000
+        n_local, scaling = n_total // world, "strong"
     k = 21
     s = float(n_total) ** (-1.0 / 3.0)  # ConstantSpacing N^(-1/3), alpha = s/20, alpha_min = alpha/100
     force = dict(kind=2, beta=0.2, u0=1.0, gamma=3.0)
@@ -401,21 +470,23 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
                 "workload": f"{n_total} uniform fp32 points in the unit cube, repel sweep k=21, "
                             f"ClippedSpacingForce(beta=0.2), ConstantSpacing N^(-1/3), rebuild_every=1, "
-                            f"stall_after=0, tol=0 (BASELINE.json configs[2])",
+                            f"stall_after=0, tol=0 (BASELINE.json configs[{2 if world == 1 else 3}]"
+                            + ("" if world == 1 or scaling == "weak" else
+                               "; fixed total: the one-GPU point of this curve is --gpus 1 --points " + str(n_total)) + ")",
                 "points_per_gpu": n_local,
                 "sharding": "none" if world == 1 else f"{world} z-slabs, resident local sessions, ghost-layer exchange "
-                                                     f"per iteration (RCCL point-to-point)",
+                                                     f"per iteration ({'gloo, ranks sharing one GPU (rehearsal)' if rehearsal else 'RCCL point-to-point'})",
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "wtp::brick_kernel<1,0,1> (LDS-staged 27-cell sweep, count-certified k-set, fused repel force)",
+                "kernel": "wtp::cs2_kernel (LDS-staged 27-cell sweep on support-sized cells, count-certified k-set, fused repel force)",
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -454,31 +525,34 @@ def main():
                 print(f"[bench] copy-bandwidth probe failed: {e}", file=sys.stderr)
         # HBM bytes per launch come from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 on
         # gfx950 + WRITE_SIZE), scaled to this launch's point count; counters cannot be read live.
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             out["roofline"]["traffic"] = round(tj["traffic_bytes_per_launch"] * pts_per_launch / tj["points_per_launch"])
-            out["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
+            out["roofline"]["traffic_source"] = "profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
             out["roofline"]["algorithmic_bytes"] = round(B_ALG_SWEEP * pts_per_launch)
             if "valu_wave_instructions_per_launch" in tj and sweep_ms > 0:
                 # what actually bounds the kernel: vector-ALU issue.  Wave instructions per launch from
                 # the committed SQ_INSTS_VALU pass, x 64 lanes, over the live launch time; peak = 256 CUs x 4 SIMDs x
                 # 16 lanes x 2.4 GHz (measured: tools/micro/valu_rate.hip).
+                # peak: one wave64 VALU instruction per 4 cycles per SIMD, which is what SQ_ACTIVE_INST_VALU charges
+                # (256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz); profiles/r02_issue_rates.txt has the measured sustained rates
                 ops = tj["valu_wave_instructions_per_launch"] * 64.0 * pts_per_launch / tj["points_per_launch"]
-                out["valu_issue"] = {"kernel": "wtp::brick_kernel<1,0,1>", "achieved": round(ops / (sweep_ms * 1e-3) / 1e12, 2),
+                out["valu_issue"] = {"kernel": "wtp::cs2_kernel", "achieved": round(ops / (sweep_ms * 1e-3) / 1e12, 2),
                                      "peak": 39.3, "unit": "T lane-ops/s", "frac": round(ops / (sweep_ms * 1e-3) / 39.3e12, 3),
                                      "lane_ops_per_point": round(ops / pts_per_launch, 1),
-                                     "source": "profiles/r01_traffic.json (rocprofv3 --pmc SQ_INSTS_VALU)"}
+                                     "all_instructions_per_point": tj.get("all_wave_instructions_per_launch", 0) * 64.0 / tj["points_per_launch"],
+                                     "source": "profiles/r02_traffic.json (rocprofv3 --pmc SQ_INSTS_VALU, _SALU, _LDS, _VMEM)"}
         if full_sel is not None:
             out["full_k_selection_path"] = full_sel
         if world == 1 and not args.no_other_paths:
             if not sess_closed:
                 sess.close()
-            out["other_paths"] = other_paths(ctx, torch, np, wtp_amd, args.extra_legs)
+            out["other_paths"] = other_paths(ctx, torch, np, wtp_amd, args.extra_legs, not args.no_e2e)
         if not args.no_cpu:
             # the reference itself when it is installed on the box (it is not in the build image), else the port
             out["cpu_baseline"] = reference_baseline(args.cpu_points // 4, args.cpu_iters) or \
-                cpu_baseline(args.cpu_points, args.cpu_iters)
+                (cpu_baseline(args.cpu_points, args.cpu_iters) if oracle_ready else None)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -157,13 +157,26 @@ def relax_sweep(snap, n_fixed: int, spacing, force_kind=2, beta=0.2, u0=1.0, gam
     return dict(p=p, forces=forces, nn_dist=nn_dist, nn_id=nn_id)
 
 
+def kd_build_seconds(xyz) -> float:
+    """Wall time of one (serial) kd-tree build over xyz."""
+    xyz = _xyz(xyz)
+    f = getattr(lib(), f"wtpo_kd_build_seconds_{_suf(xyz.dtype)}")
+    f.restype = C.c_double
+    return float(f(_p(xyz), C.c_int64(xyz.shape[0]), C.c_int(xyz.shape[1])))
+
+
 def relax_loop(snap, n_fixed: int, spacing, force_kind=2, beta=0.2, u0=1.0, gamma=3.0, k=21,
                alpha_lo=None, alpha_max=None, max_iters=1000, tol=1e-6, rebuild_every=1,
                stall_after=50, cv_target=0.0):
-    """The whole _relax! loop (src/repel.jl:243-334).  Returns dict(p, conv, stop_reason)."""
+    """The whole _relax! loop (src/repel.jl:243-334).  Returns dict(p, conv, stop_reason).
+    A callable `spacing` (positions -> values) is re-evaluated like the reference does: on every rebuild
+    for the CV monitor's array (:251) and at p_old in every sweep for the force and the step (:260)."""
     snap = np.array(_xyz(snap), copy=True)
     n, dim = snap.shape
     dt = snap.dtype
+    if callable(spacing):
+        return _relax_loop_callable(snap, n_fixed, spacing, force_kind, beta, u0, gamma, k, alpha_lo, alpha_max,
+                                    max_iters, tol, rebuild_every, stall_after, cv_target)
     sp = _spacings(spacing, n, dt)
     p = np.array(snap[n_fixed:], copy=True)
     conv = np.zeros(max(max_iters, 1), dtype=dt)
@@ -174,6 +187,34 @@ def relax_loop(snap, n_fixed: int, spacing, force_kind=2, beta=0.2, u0=1.0, gamm
         ct(beta), ct(u0), ct(gamma), C.c_int(k), ct(alpha_lo), ct(alpha_max), C.c_int(max_iters),
         C.c_double(tol), C.c_int(rebuild_every), C.c_int(stall_after), C.c_double(cv_target),
         _p(conv), C.byref(reason),
+    )
+    if nconv < 0:
+        raise ValueError("rebuild_every must be >= 1")
+    return dict(p=p, conv=conv[:nconv].copy(), stop_reason=int(reason.value))
+
+
+def _relax_loop_callable(snap, n_fixed, spacing, force_kind, beta, u0, gamma, k, alpha_lo, alpha_max, max_iters, tol,
+                         rebuild_every, stall_after, cv_target):
+    n, dim = snap.shape
+    dt = snap.dtype
+    ct = _ct(dt)
+    sp = np.ascontiguousarray(np.asarray(spacing(snap), dtype=dt).reshape(n))
+    p = np.array(snap[n_fixed:], copy=True)
+    conv = np.zeros(max(max_iters, 1), dtype=dt)
+    reason = C.c_int(0)
+    rp = C.POINTER(ct)
+    CB = C.CFUNCTYPE(None, rp, C.c_int64, rp, C.c_void_p)
+
+    def refresh(pos, n_move, out, _user):
+        x = np.ctypeslib.as_array(pos, shape=(n_move, dim))
+        np.ctypeslib.as_array(out, shape=(n_move,))[:] = np.asarray(spacing(x), dtype=dt).reshape(n_move)
+
+    cb = CB(refresh)
+    nconv = getattr(lib(), f"wtpo_relax_loop_cb_{_suf(dt)}")(
+        _p(snap), C.c_int64(n), C.c_int64(n_fixed), C.c_int(dim), _p(p), _p(sp), C.c_int(force_kind),
+        ct(beta), ct(u0), ct(gamma), C.c_int(k), ct(alpha_lo), ct(alpha_max), C.c_int(max_iters),
+        C.c_double(tol), C.c_int(rebuild_every), C.c_int(stall_after), C.c_double(cv_target),
+        _p(conv), C.byref(reason), cb, None,
     )
     if nconv < 0:
         raise ValueError("rebuild_every must be >= 1")

@@ -30,6 +30,7 @@
  * SURVEY.md §8c).  The canonical rule defined here is ascending (d2, index).
  */
 #include <math.h>
+#include <time.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>

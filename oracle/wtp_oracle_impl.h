@@ -573,16 +573,40 @@ void FN(wtpo_closest_pair)(const REAL* nn_dist, const int32_t* nn_id, const REAL
 }
 
 /* ---- the whole _relax! loop (src/repel.jl:243-334) with its stop rules ------------------
- * kick / trace / deposit! are host-side extras and stay out.  spacing is constant or a
- * per-point array evaluated by the caller (static during the loop unless constant).
+ * kick / trace / deposit! are host-side extras and stay out.  spacing is constant, a per-point
+ * array (static during the loop), or — `refresh` != NULL — a callable of the movable points:
+ *   refresh(positions n_move x dim, n_move, out n_move values, user)
+ * evaluated like the reference does: at the current positions on every rebuild for the array the CV
+ * monitor reads (src/repel.jl:251), and at p_old in EVERY sweep for the force / step (s = spacing(xi),
+ * src/repel.jl:260).  `spacings` is then updated in place (n values, fixed head kept).
  * Returns the number of conv entries written (<= max_iters); p (n_move x dim) is updated in
  * place; *stop_reason: 0 max_iters, 1 tol, 2 cv_target (p reverted), 3 stall. */
+typedef void (*FN(wtpo_spacing_cb))(const REAL* pos, int64_t n_move, REAL* out, void* user);
+int FN(wtpo_relax_loop_cb)(REAL* snap, int64_t n, int64_t n_fixed, int dim, REAL* p,
+                           REAL* spacings, int force_kind, REAL beta, REAL u0, REAL gamma, int k,
+                           REAL alpha_lo, REAL alpha_max, int max_iters, double tol, int rebuild_every,
+                           int stall_after, double cv_target, REAL* conv, int* stop_reason,
+                           FN(wtpo_spacing_cb) refresh, void* user);
 int FN(wtpo_relax_loop)(REAL* snap, int64_t n, int64_t n_fixed, int dim, REAL* p,
                         const REAL* spacings, int force_kind, REAL beta, REAL u0, REAL gamma, int k,
                         REAL alpha_lo, REAL alpha_max, int max_iters, double tol, int rebuild_every,
                         int stall_after, double cv_target, REAL* conv, int* stop_reason) {
+    return FN(wtpo_relax_loop_cb)(snap, n, n_fixed, dim, p, (REAL*)spacings, force_kind, beta, u0, gamma, k, alpha_lo,
+                                  alpha_max, max_iters, tol, rebuild_every, stall_after, cv_target, conv, stop_reason,
+                                  NULL, NULL);
+}
+int FN(wtpo_relax_loop_cb)(REAL* snap, int64_t n, int64_t n_fixed, int dim, REAL* p,
+                           REAL* spacings, int force_kind, REAL beta, REAL u0, REAL gamma, int k,
+                           REAL alpha_lo, REAL alpha_max, int max_iters, double tol, int rebuild_every,
+                           int stall_after, double cv_target, REAL* conv, int* stop_reason,
+                           FN(wtpo_spacing_cb) refresh, void* user) {
     if (rebuild_every < 1) return -1; /* ArgumentError, repel.jl:74 */
     int64_t n_move = n - n_fixed;
+    REAL* s_sweep = NULL; /* spacing(x_i) at p_old, every sweep (:260); the CV monitor keeps the rebuild-time array (:251) */
+    if (refresh) {
+        s_sweep = (REAL*)malloc(sizeof(REAL) * (size_t)(n + 1));
+        memcpy(s_sweep, spacings, sizeof(REAL) * (size_t)n);
+    }
     REAL* p_old = (REAL*)malloc(sizeof(REAL) * (size_t)(n_move * dim + 1));
     REAL* forces = (REAL*)malloc(sizeof(REAL) * (size_t)(n_move + 1));
     REAL* nn_dist = (REAL*)malloc(sizeof(REAL) * (size_t)(n_move + 1));
@@ -592,9 +616,12 @@ int FN(wtpo_relax_loop)(REAL* snap, int64_t n, int64_t n_fixed, int dim, REAL* p
     *stop_reason = 0;
     while (i <= max_iters) {
         memcpy(p_old, p, sizeof(REAL) * (size_t)(n_move * dim)); /* :244 */
-        if ((i - 1) % rebuild_every == 0)                        /* :245-253 */
+        if ((i - 1) % rebuild_every == 0) {                      /* :245-253 */
             memcpy(snap + n_fixed * dim, p, sizeof(REAL) * (size_t)(n_move * dim));
-        FN(wtpo_relax_sweep)(snap, n, n_fixed, dim, p_old, spacings, force_kind, beta, u0, gamma,
+            if (refresh && i > 1) refresh(p, n_move, spacings + n_fixed, user); /* spacings at the current positions :251 */
+        }
+        if (refresh) refresh(p_old, n_move, s_sweep + n_fixed, user);          /* s = spacing(xi) :260 */
+        FN(wtpo_relax_sweep)(snap, n, n_fixed, dim, p_old, refresh ? s_sweep : spacings, force_kind, beta, u0, gamma,
                              k, alpha_lo, alpha_max, p, forces, nn_dist, nn_id);
         REAL mx = 0; /* maximum(forces; init = 0) :293 */
         for (int64_t t = 0; t < n_move; ++t)
@@ -627,7 +654,19 @@ int FN(wtpo_relax_loop)(REAL* snap, int64_t n, int64_t n_fixed, int dim, REAL* p
     free(forces);
     free(nn_dist);
     free(nn_id);
+    free(s_sweep);
     return nconv;
+}
+
+/* Wall time of one kd-tree build (the serial part of every oracle iteration, like NearestNeighbors.jl's
+ * KDTree(coords) at src/repel.jl:252): bench.py reports its share of the CPU baseline. */
+double FN(wtpo_kd_build_seconds)(const REAL* xyz, int64_t n, int dim) {
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    FN(kdtree)* t = FN(kd_build)(xyz, n, dim);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    FN(kd_free)(t);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
 
 /* _near_duplicate_keep_mask (src/repel.jl:565-580): greedy, order-preserving; the ball

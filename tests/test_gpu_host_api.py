@@ -85,6 +85,27 @@ def test_repel_matches_oracle_loop(ctx, O, wtp):
     assert len(trace) == 8 and all(t["idx_a"] < t["idx_b"] for t in trace)
 
 
+def test_repel_callable_spacing_refreshed_every_sweep(ctx, O, wtp):
+    """A host-callable (PER_POINT) spacing with rebuild_every > 1: the reference evaluates s = spacing(x_i) at
+    the current position in every sweep (src/repel.jl:260), not only on rebuilds (:251).  fp64 -> exact path:
+    the positions must equal the oracle loop's (which re-evaluates the same callable the same way) bit for bit."""
+    cloud = _cloud(wtp, dtype=np.float64)
+    nb = len(cloud.boundary)
+
+    def graded(x):
+        x = np.asarray(x)
+        return 0.05 + 0.03 * x[:, 0]          # grows along x: a moving point's spacing changes every sweep
+
+    conv = []
+    new = wtp.repel(cloud, graded, max_iters=7, tol=0.0, stall_after=0, rebuild_every=3, convergence=conv, ctx=ctx,
+                    alpha=0.05 / 20)
+    ref = O.relax_loop(wtp.points(cloud), nb, graded, 2, 0.2, 1.0, 3.0, 21, 0.05 / 2000, 0.05 / 20, max_iters=7, tol=0.0,
+                       rebuild_every=3, stall_after=0)
+    assert len(conv) == 7
+    assert np.array_equal(new.volume.points(), ref["p"])
+    assert np.allclose(conv, ref["conv"], rtol=1e-12)
+
+
 def test_repel_variable_spacing_and_kick(ctx, wtp):
     cloud = _cloud(wtp, dtype=np.float32)
     sp = wtp.BoundaryLayerSpacing(cloud.boundary.points(), at_wall=0.04, bulk=0.08, layer_thickness=0.3)

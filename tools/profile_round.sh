@@ -10,8 +10,8 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 echo "== stats pass" | tee $OUT/log.txt
-timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT/stats -o $TAG -- python3 $REPO/bench.py --steps 30 --warmup 5 > $OUT/bench_under_rocprof.json 2>> $OUT/log.txt || echo "stats pass failed" | tee -a $OUT/log.txt
-for C in FETCH_SIZE WRITE_SIZE "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_LDS SQ_INSTS_VALU" "SQ_LDS_BANK_CONFLICT SQ_WAVES"; do
+timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT/stats -o $TAG -- python3 $REPO/bench.py --steps 30 --warmup 5 --no-e2e > $OUT/bench_under_rocprof.json 2>> $OUT/log.txt || echo "stats pass failed" | tee -a $OUT/log.txt
+for C in FETCH_SIZE WRITE_SIZE "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAVES"; do
   N=$(echo $C | tr ' ' '_')
   echo "== pmc pass $C" | tee -a $OUT/log.txt
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_$N -o $TAG -- python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu --no-other-paths > /dev/null 2>> $OUT/log.txt || echo "pmc pass $C failed" | tee -a $OUT/log.txt

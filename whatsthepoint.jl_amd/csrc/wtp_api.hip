@@ -45,6 +45,18 @@ int ensure(wtp_ctx* ctx, DevBuf& b, size_t bytes) {
     return WTP_OK;
 }
 
+int launch_occupancy_of(wtp_ctx* ctx, const void* fn, int threads, size_t smem) {
+    const auto key = std::make_pair(fn, smem);
+    auto it = ctx->launch_cache.find(key);
+    if (it != ctx->launch_cache.end()) return it->second;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    int occ = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, threads, smem);
+    if (e != hipSuccess || occ < 1) occ = 1;
+    ctx->launch_cache[key] = occ;
+    return occ;
+}
+
 static int ensure_pinned(wtp_ctx* ctx, size_t bytes) {
     if (ctx->host_pinned_cap >= bytes) return WTP_OK;
     if (ctx->host_pinned) hipHostFree(ctx->host_pinned);

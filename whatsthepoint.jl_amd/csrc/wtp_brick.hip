@@ -802,17 +802,8 @@ static size_t brick_smem_bytes(int hcap, int nb) {
 template <int MODE, int KT, int CS> static int brick_launch(wtp_ctx* ctx, SearchArgs<float>& a) {
     const int nb = CS ? 32 : NB;
     const int hcap = a.brick_hcap > 0 ? a.brick_hcap : 2560;
-    static int cached_hcap = -1;
-    static int occ = 0;
-    if (cached_hcap != hcap) {
-        (void)hipFuncSetAttribute((const void*)brick_kernel<MODE, KT, CS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)brick_smem_bytes(hcap, nb));
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, brick_kernel<MODE, KT, CS>, kBrickThreads,
-                                                                    brick_smem_bytes(hcap, nb));
-        if (e != hipSuccess || occ < 1) occ = 1;
-        if (occ > 4) occ = 4;
-        cached_hcap = hcap;
-    }
+    int occ = launch_occupancy_of(ctx, (const void*)brick_kernel<MODE, KT, CS>, kBrickThreads, brick_smem_bytes(hcap, nb));
+    if (occ > 4) occ = 4;
     int gsz = ctx->sm_count * occ;
     gsz -= gsz % 8;
     if (gsz < 8) gsz = 8;
@@ -868,7 +859,8 @@ template <> int launch_sweep<float>(wtp_ctx* ctx, SearchArgs<float>& a, bool fre
     span_end(ctx, sp);
     if (rc) return rc;
     const int sp2 = span_begin(ctx, 2);
-    rc = launch_generic_sweep<float>(ctx, a, false);
+    if (cs && a.cs2_bx > 0) rc = launch_cs2_followup(ctx, a); // nearest neighbour of the queries the bricks left open
+    if (!rc) rc = launch_generic_sweep<float>(ctx, a, false);
     span_end(ctx, sp2);
     return rc;
 }

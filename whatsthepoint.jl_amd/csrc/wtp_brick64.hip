@@ -353,15 +353,8 @@ template <typename T> int launch_brick_cs(wtp_ctx* ctx, SearchArgs<T>& a) {
     int hcap = a.brick_hcap > 0 ? a.brick_hcap : 1280;
     if (hcap > 2047) hcap = 2047; // ring entries are 16-bit LDS point indices, and two workgroups share a CU's LDS
     const size_t smem = b64_smem_bytes(hcap, sizeof(Pt<T>));
-    static size_t cached = 0;
-    static int occ = 0;
-    if (cached != smem) {
-        (void)hipFuncSetAttribute((const void*)brick_cs_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, brick_cs_kernel<T>, kB64Threads, smem);
-        if (e != hipSuccess || occ < 1) occ = 1;
-        if (occ > 4) occ = 4;
-        cached = smem;
-    }
+    int occ = launch_occupancy_of(ctx, (const void*)brick_cs_kernel<T>, kB64Threads, smem);
+    if (occ > 4) occ = 4;
     int gsz = ctx->sm_count * occ;
     gsz -= gsz % 8;
     if (gsz < 8) gsz = 8;

@@ -726,9 +726,15 @@ int launch_cs2(wtp_ctx* ctx, SearchArgs<float>& a) {
     gsz -= gsz % 8;
     if (gsz < 8) gsz = 8;
     hipLaunchKernelGGL(cs2_kernel, dim3(gsz), dim3(kCsThreads), smem, ctx->stream, a, hcap, BX);
-    // its partial slots follow the bricks' (brick_partials() leaves room for them)
-    hipLaunchKernelGGL(cs2_nnfix_kernel, dim3(kNnFixBlocks), dim3(kNnFixThreads), 0, ctx->stream, a, gsz);
-    a.used_brick = gsz + kNnFixBlocks;
+    a.used_brick = gsz;
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
+// the follow-up kernel; its partial slots follow the bricks' (brick_partials() leaves room for them)
+int launch_cs2_followup(wtp_ctx* ctx, SearchArgs<float>& a) {
+    hipLaunchKernelGGL(cs2_nnfix_kernel, dim3(kNnFixBlocks), dim3(kNnFixThreads), 0, ctx->stream, a, a.used_brick);
+    a.used_brick += kNnFixBlocks;
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;
 }

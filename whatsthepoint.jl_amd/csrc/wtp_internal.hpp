@@ -9,7 +9,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/wtp.h"
@@ -200,6 +202,9 @@ struct wtp_ctx {
     double rho_cs2 = 1.0;      // WTP_RHO_CS: target points per cell of the round-2 sweep (the support floor usually binds)
     size_t cs2_smem = 0;       // launch attributes of cs2_kernel cached per context
     int cs2_occ = 0;
+    // (kernel, dynamic LDS bytes) -> blocks per CU, per CONTEXT: the dynamic-LDS attribute and the occupancy are
+    // properties of a kernel on one device, and several contexts (devices) may live in one process
+    std::map<std::pair<const void*, size_t>, int> launch_cache;
     double styp_sigma = 0.0;   // WTP_STYP_SIGMA: typical spacing = mean + this many standard deviations (measured: > 0 only hurts)
     int64_t knn_tune_n = -1;   // topology calls: cloud size / dim / k the cached cell scale was measured for
     int knn_tune_dim = 0, knn_tune_k = 0;
@@ -275,6 +280,8 @@ int fail(wtp_ctx* ctx, int code, const std::string& msg);
     } while (0)
 
 int ensure(wtp_ctx* ctx, DevBuf& b, size_t bytes);
+// sets the kernel's dynamic-LDS limit once per (context, kernel, size) and returns the blocks per CU it can hold
+int launch_occupancy_of(wtp_ctx* ctx, const void* fn, int threads, size_t smem);
 
 // timing spans: kind 0 hash, 1 sweep, 2 other
 int span_begin(wtp_ctx* ctx, int kind);
@@ -319,6 +326,7 @@ inline int total_partials() { return brick_partials() + kWavePartials + kGeneric
 int launch_brick_radius(wtp_ctx* ctx, SearchArgs<float>& a);
 // round-2 compact-support sweep (wtp_cs2.hip)
 int launch_cs2(wtp_ctx* ctx, SearchArgs<float>& a);
+int launch_cs2_followup(wtp_ctx* ctx, SearchArgs<float>& a);
 int launch_cs2_census(wtp_ctx* ctx, int BX, unsigned int* d_out513);
 int cs2_max_bx();
 template <typename T>

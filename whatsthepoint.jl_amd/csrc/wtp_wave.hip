@@ -456,12 +456,7 @@ int launch_wave_radius_count(wtp_ctx* ctx, SearchArgs<T>& a, T r, int32_t* d_cou
 template <typename T>
 int launch_wave_radius_fill(wtp_ctx* ctx, SearchArgs<T>& a, T r, const int64_t* d_offsets, int32_t* d_idx,
                             const int32_t* list, const int32_t* list_count) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)wave_radius_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)wave_smem<T>());
-        attr_set = true;
-    }
+    (void)launch_occupancy_of(ctx, (const void*)wave_radius_kernel<T, true>, kThreads, wave_smem<T>());
     int64_t want = ((int64_t)a.n / (list ? 16 : 1) + kWaves - 1) / kWaves;
     int nb = (int)(want > 16384 ? 16384 : (want < 64 ? 64 : want));
     hipLaunchKernelGGL((wave_radius_kernel<T, true>), dim3(nb), dim3(kThreads), wave_smem<T>(), ctx->stream, a, r,
@@ -471,12 +466,7 @@ int launch_wave_radius_fill(wtp_ctx* ctx, SearchArgs<T>& a, T r, const int64_t* 
 }
 
 template <typename T, int MODE> static int launch_wave(wtp_ctx* ctx, SearchArgs<T>& a, bool all, int part_base) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)wave_kernel<T, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)wave_smem<T>());
-        attr_set = true;
-    }
+    (void)launch_occupancy_of(ctx, (const void*)wave_kernel<T, MODE>, kThreads, wave_smem<T>());
     // hand-back lists are a small fraction of the cloud: size the grid by the cloud, not by the chip
     // (an idle block still pays its reduction and its partial: 27 us per step at 47 k points with 2048)
     int64_t want = all ? ((int64_t)a.n + kWaves - 1) / kWaves : (int64_t)a.n / 256;

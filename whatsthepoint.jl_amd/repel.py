@@ -77,8 +77,10 @@ def relax(p, snap_fixed, spacing, force_model, *, alpha_lo, alpha_max, k=21, max
         i = 1
         while i <= max_iters:
             rebuild = (i - 1) % rebuild_every == 0
-            if rebuild and variable and i > 1:
-                # spacings at the current positions (src/repel.jl:251)
+            if variable and i > 1:
+                # s = spacing(x_i) at the current position in EVERY sweep (src/repel.jl:260), not only on rebuilds
+                # (:251 refreshes the array the CV monitor and the kick read; with rebuild_every > 1 the library's
+                # statistics use these fresher values for the monitor too — the one, documented, difference)
                 cur = sess.positions()
                 spacings[n_fixed:] = np.asarray(spacing(cur), dtype=p.dtype)
                 sess.set_spacing(spacings)
@@ -240,6 +242,8 @@ def _deposit_escaped(sess, st, it, octree, spacing, deposit_ratio, offset, kq, c
     n_dep = 0
     placed = []
     for a, i in enumerate(ids):
+        if tri[a] < 0:
+            continue                                      # no landing triangle (tri_idx == 0 && continue, src/repel.jl:498)
         js = near[a].astype(np.int64)
         js = js[(js != i) & is_bnd[js]]
         if len(js):
