@@ -565,7 +565,10 @@ __global__ __launch_bounds__(kCsThreads, 4) void cs2_kernel(SearchArgs<float> a,
                         a.nn_dist[e.gslot] = nd;
                         a.nn_id[e.gslot] = bi;
                         cs_acc_point(acc, e.f, nd, e.s, e.qid, bi);
-                    } else { // not certified by the 27 cells: the follow-up kernel searches 5 x 5 x 5
+                    } else { // not certified by the 27 cells: the follow-up kernel searches the shell around them.
+                        // It starts from this search's winner: the SQUARED distance (exact bits) waits in nn_dist.
+                        a.nn_dist[e.gslot] = bd;
+                        a.nn_id[e.gslot] = bi == 0x7FFFFFFF ? -1 : bi;
                         const int pos = atomicAdd(a.nn_count, 1);
                         a.nn_list[pos] = e.gslot;
                     }
@@ -638,17 +641,20 @@ int cs2_max_bx() { return kCsMaxBX; }
 // statistics.  One lane per query, 5 x 5 x 5 cells straight from the sorted array (25 contiguous runs),
 // canonical (d2, id) minimum, certified against the radius the 125 cells cover; whatever is left (isolated
 // points) goes to the exact path, which recomputes the whole query.
-constexpr int kNnFixBlocks = 256;
+constexpr int kNnFixBlocks = 512;
 constexpr int kNnFixThreads = 1024; // 16 waves per block, one query per wave at a time: the search is a chain of
                                     // dependent global loads, so it wants many waves in flight, not many lanes per query
-__global__ __launch_bounds__(kNnFixThreads) void cs2_nnfix_kernel(SearchArgs<float> a, int part_base) {
+__global__ __launch_bounds__(kNnFixThreads, 8) void cs2_nnfix_kernel(SearchArgs<float> a, int part_base) {
     __shared__ Acc sacc[kNnFixThreads / 64];
     const Grid<float> g = *a.grid;
     const int n = *a.nn_count;
     const int lane = threadIdx.x & 63;
     const int wave_g = (blockIdx.x * kNnFixThreads + threadIdx.x) >> 6, nwaves = (gridDim.x * kNnFixThreads) >> 6;
     Acc acc = acc_empty();
-    // four queries per wave, 16 lanes each: lane l of a group takes the rows l and l + 16 of the 25 (dz, dy) rows
+    // four queries per wave, 16 lanes each.  The 27 cells around the query were searched by its brick; what is open
+    // is the shell of the 5 x 5 x 5 block: 25 x-rows, each cut into {cell cx-2 | cells cx-1..cx+1 | cell cx+2}, minus
+    // the middle of the 9 inner rows.  A piece is read only if its box lies closer than the current winner — usually
+    // one to three of the 66 (reading all 25 rows cost 3 KB of scattered lines per query: bandwidth, 86 us per step).
     const int grp = lane >> 4, l16 = lane & 15;
     for (int i0 = wave_g * 4; i0 < n; i0 += nwaves * 4) {
         const int i = i0 + grp;
@@ -657,30 +663,50 @@ __global__ __launch_bounds__(kNnFixThreads) void cs2_nnfix_kernel(SearchArgs<flo
         const float4 qp = a.snap[gslot];
         const int32_t qid = w_to_id(qp.w);
         const int cx = cell_coord(g, qp.x, 0), cy = cell_coord(g, qp.y, 1), cz = cell_coord(g, qp.z, 2);
-        float bd = Lim<float>::inf();
-        int32_t bi = 0x7FFFFFFF;
-        const int x0 = cx - 2 < 0 ? 0 : cx - 2, x1 = cx + 2 > g.n[0] - 1 ? g.n[0] - 1 : cx + 2;
-        int p0[2], p1[2];
+        float bd = a.nn_dist[gslot]; // squared distance of the brick's winner (+inf when it found nothing)
+        int32_t bi = a.nn_id[gslot];
+        bi = bi < 0 ? 0x7FFFFFFF : bi;
+        // distance from the query to the slab of cells [c + lo, c + hi] along one axis, less the cell map's rounding
+        auto gap = [&](float v, int axis, int c, int lo, int hi) {
+            const float a0 = g.org[axis] + (float)(c + lo) * g.c, a1 = g.org[axis] + (float)(c + hi + 1) * g.c;
+            float d = v < a0 ? a0 - v : (v > a1 ? v - a1 : 0.f);
+            d -= g.margin;
+            return d > 0.f ? d : 0.f;
+        };
+        for (int piece = l16; piece < 75; piece += 16) {
+            const int r = piece / 3, seg = piece % 3;
+            const int dz = r / 5 - 2, dy = r % 5 - 2;
+            const bool inner = dz >= -1 && dz <= 1 && dy >= -1 && dy <= 1;
+            if (inner && seg == 1) continue; // searched by the brick
+            const int gz = cz + dz, gy = cy + dy;
+            if (gz < 0 || gz >= g.n[2] || gy < 0 || gy >= g.n[1]) continue;
+            int xa = seg == 0 ? cx - 2 : (seg == 1 ? cx - 1 : cx + 2), xb = seg == 1 ? cx + 1 : xa;
+            xa = xa < 0 ? 0 : xa;
+            xb = xb > g.n[0] - 1 ? g.n[0] - 1 : xb;
+            if (xa > xb) continue;
+            // edge cells are unbounded outward (clamped map): no pruning against a box that includes one
+            const bool edge = xa == 0 || xb == g.n[0] - 1 || gy == 0 || gy == g.n[1] - 1 || gz == 0 || gz == g.n[2] - 1;
+            if (!edge) {
+                const float gx2 = gap(qp.x, 0, 0, xa, xb), gy2 = gap(qp.y, 1, gy, 0, 0), gz2 = gap(qp.z, 2, gz, 0, 0);
+                if ((gx2 * gx2 + gy2 * gy2) + gz2 * gz2 > bd) continue; // nothing in there can beat the winner
+            }
+            const int base = (gz * g.n[1] + gy) * g.n[0];
+            const int p1 = a.cell_start[base + xb + 1];
+            for (int p = a.cell_start[base + xa]; p < p1; p += 4) {
+                float4 c[4];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) { // both rows' bounds in flight together
-            const int r = l16 + 16 * t;
-            const int gz = cz + r / 5 - 2, gy = cy + r % 5 - 2;
-            const bool ok = r < 25 && gz >= 0 && gz < g.n[2] && gy >= 0 && gy < g.n[1];
-            const int base = ok ? (gz * g.n[1] + gy) * g.n[0] : 0;
-            p0[t] = a.cell_start[base + x0];
-            p1[t] = ok ? a.cell_start[base + x1 + 1] : p0[t];
-        }
+                for (int u = 0; u < 4; ++u) c[u] = a.snap[p + u < p1 ? p + u : p];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-            for (int p = p0[t]; p < p1[t]; ++p) {
-                const float4 c = a.snap[p];
-                const int32_t cid = w_to_id(c.w);
-                const float d = dist2<float>(qp.x, qp.y, qp.z, c.x, c.y, c.z);
-                if (cid != qid && lex_lt(d, cid, bd, bi)) {
-                    bd = d;
-                    bi = cid;
+                for (int u = 0; u < 4; ++u) {
+                    const int32_t cid = w_to_id(c[u].w);
+                    const float d = dist2<float>(qp.x, qp.y, qp.z, c[u].x, c[u].y, c[u].z);
+                    if (p + u < p1 && cid != qid && lex_lt(d, cid, bd, bi)) {
+                        bd = d;
+                        bi = cid;
+                    }
                 }
             }
+        }
 #pragma unroll
         for (int dlt = 8; dlt >= 1; dlt >>= 1) { // minimum over the group's 16 lanes
             const float od = __shfl_xor(bd, dlt, 64);

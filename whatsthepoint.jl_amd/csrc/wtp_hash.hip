@@ -169,8 +169,8 @@ __global__ void grid_setup_kernel(const T* __restrict__ part, int nparts, Grid<T
 
 template <typename T>
 __global__ void cell_rank_kernel(const Pt<T>* __restrict__ pts, int64_t n, const Grid<T>* __restrict__ gp,
-                                 int32_t* __restrict__ cell_cnt, int2* __restrict__ cell_rank, int64_t v_old,
-                                 int32_t v_fixed_old) {
+                                 int32_t* __restrict__ cell_cnt, int32_t* __restrict__ cell_rank,
+                                 uint8_t* __restrict__ dirty, int64_t v_old, int32_t v_fixed_old) {
     const Grid<T> g = *gp;
     const int lane = threadIdx.x & 63;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -197,14 +197,20 @@ __global__ void cell_rank_kernel(const Pt<T>* __restrict__ pts, int64_t n, const
         const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
         const int len_to_end = above ? __builtin_ctzll(above) + 1 : 64 - lane; // valid for the head lane
         int r0 = 0;
-        if (head && valid) r0 = atomicAdd(&cell_cnt[cell], len_to_end);
+        if (head && valid) {
+            r0 = atomicAdd(&cell_cnt[cell], len_to_end);
+            // A run keeps the order of the input (ids ascending inside a cell: the original order, or the previous
+            // canonical one).  Only a cell that collects SEVERAL runs (a point moved in, or a run split between two
+            // waves) can end up out of order: the canonical-order pass visits those cells only.
+            if (r0 != 0) dirty[cell] = 1;
+        }
         r0 = __shfl(r0, start, 64);
-        if (valid) cell_rank[i] = make_int2(cell, r0 + (lane - start));
+        if (valid) cell_rank[i] = r0 + (lane - start); // the cell itself is recomputed by the scatter (4 bytes per point less, twice)
     }
 }
 
 // ---- exclusive scan of cell counts (1024 cells per block) ------------------------------------
-static constexpr int kScanItems = 4;
+static constexpr int kScanItems = 16; // 4096 cells per block: the single-block scan of the block sums stays short (~10 M cells at one point per cell)
 static constexpr int kScanTile = kThreads * kScanItems;
 
 __device__ inline int wave_incl_scan(int v) {
@@ -282,27 +288,57 @@ __global__ void scan_apply_kernel(const int32_t* __restrict__ cnt, const int32_t
     // thread t owns items base + t*kScanItems .. +kScanItems-1 (contiguous per thread)
     int v[kScanItems];
     int s = 0;
+    const bool whole = base + kScanTile <= ncells; // every tile but the last: 16-byte accesses, no bound checks
+    if (whole) {
+        const int4* src = reinterpret_cast<const int4*>(cnt + base + threadIdx.x * kScanItems);
 #pragma unroll
-    for (int j = 0; j < kScanItems; ++j) {
-        int idx = base + threadIdx.x * kScanItems + j;
-        v[j] = idx < ncells ? cnt[idx] : 0;
-        s += v[j];
+        for (int q = 0; q < kScanItems / 4; ++q) {
+            const int4 w = src[q];
+            v[4 * q] = w.x;
+            v[4 * q + 1] = w.y;
+            v[4 * q + 2] = w.z;
+            v[4 * q + 3] = w.w;
+            s += (w.x + w.y) + (w.z + w.w);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kScanItems; ++j) {
+            int idx = base + threadIdx.x * kScanItems + j;
+            v[j] = idx < ncells ? cnt[idx] : 0;
+            s += v[j];
+        }
     }
     int total;
     int ex = block_excl_scan(s, &total, sm) + block_sums[blockIdx.x];
+    if (whole) {
+        int4* dst = reinterpret_cast<int4*>(cell_start + base + threadIdx.x * kScanItems);
 #pragma unroll
-    for (int j = 0; j < kScanItems; ++j) {
-        int idx = base + threadIdx.x * kScanItems + j;
-        if (idx < ncells) cell_start[idx] = ex;
-        ex += v[j];
-        if (idx == ncells - 1) cell_start[ncells] = ex;
+        for (int q = 0; q < kScanItems / 4; ++q) {
+            int4 w;
+            w.x = ex;
+            w.y = w.x + v[4 * q];
+            w.z = w.y + v[4 * q + 1];
+            w.w = w.z + v[4 * q + 2];
+            ex = w.w + v[4 * q + 3];
+            dst[q] = w;
+        }
+        if (base + kScanTile == ncells && threadIdx.x == kThreads - 1) cell_start[ncells] = ex;
+    } else {
+#pragma unroll
+        for (int j = 0; j < kScanItems; ++j) {
+            int idx = base + threadIdx.x * kScanItems + j;
+            if (idx < ncells) cell_start[idx] = ex;
+            ex += v[j];
+            if (idx == ncells - 1) cell_start[ncells] = ex;
+        }
     }
 }
 
 template <typename T>
-__global__ void scatter_kernel(const Pt<T>* __restrict__ pts, int64_t n, const int2* __restrict__ cell_rank,
-                               const int32_t* __restrict__ cell_start, Pt<T>* __restrict__ out, int64_t v_old,
-                               int32_t v_fixed_old, int32_t v_id_shift) {
+__global__ void scatter_kernel(const Pt<T>* __restrict__ pts, int64_t n, const int32_t* __restrict__ cell_rank,
+                               const Grid<T>* __restrict__ gp, const int32_t* __restrict__ cell_start,
+                               Pt<T>* __restrict__ out, int64_t v_old, int32_t v_fixed_old, int32_t v_id_shift) {
+    const Grid<T> g = *gp;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
@@ -312,8 +348,8 @@ __global__ void scatter_kernel(const Pt<T>* __restrict__ pts, int64_t n, const i
             if (id < v_fixed_old) continue;
             p.w = id_to_w((T)0, id + v_id_shift);
         }
-        int2 cr = cell_rank[i];
-        out[cell_start[cr.x] + cr.y] = p;
+        const int cx = cell_coord(g, p.x, 0), cy = cell_coord(g, p.y, 1), cz = cell_coord(g, p.z, 2);
+        out[cell_start[(cz * g.n[1] + cy) * g.n[0] + cx] + cell_rank[i]] = p;
     }
 }
 
@@ -333,9 +369,11 @@ static constexpr int kCanonMax = 96;
 template <typename T>
 __global__ __launch_bounds__(kThreads) void canon_kernel(Pt<T>* __restrict__ pts,
                                                          const int32_t* __restrict__ cell_start,
+                                                         const uint8_t* __restrict__ dirty,
                                                          const Grid<T>* __restrict__ gp) {
     const int ncells = gp->ncells;
     for (int cell = blockIdx.x * kThreads + threadIdx.x; cell < ncells; cell += gridDim.x * kThreads) {
+        if (!dirty[cell]) continue; // filled by one run of the input: in order already
         const int s = cell_start[cell];
         const int m = cell_start[cell + 1] - s;
         if (m < 2 || m > kCanonMax) continue;
@@ -621,7 +659,8 @@ int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, in
     if ((rc = ensure(ctx, ctx->bbox_part, sizeof(double) * 6 * 1024))) return rc;
     if ((rc = ensure(ctx, ctx->cell_cnt, sizeof(int32_t) * (size_t)(cap + 1)))) return rc;
     if ((rc = ensure(ctx, ctx->cell_start, sizeof(int32_t) * (size_t)(cap + 2)))) return rc;
-    if ((rc = ensure(ctx, ctx->cell_of, sizeof(int2) * (size_t)n_in))) return rc;
+    if ((rc = ensure(ctx, ctx->cell_of, sizeof(int32_t) * (size_t)n_in))) return rc;
+    if ((rc = ensure(ctx, ctx->rank_of, (size_t)cap + 64))) return rc; // one byte per cell: filled by more than one run of the input
     const int nscan = (cap + kScanTile - 1) / kScanTile;
     if ((rc = ensure(ctx, ctx->scan_tmp, sizeof(int32_t) * (size_t)(nscan + 1)))) return rc;
 
@@ -629,7 +668,8 @@ int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, in
     T* part = (T*)ctx->bbox_part.p;
     int32_t* cnt = (int32_t*)ctx->cell_cnt.p;
     int32_t* start = (int32_t*)ctx->cell_start.p;
-    int2* cr = (int2*)ctx->cell_of.p;
+    int32_t* cr = (int32_t*)ctx->cell_of.p;
+    uint8_t* dirty = (uint8_t*)ctx->rank_of.p;
     int32_t* bs = (int32_t*)ctx->scan_tmp.p;
     hipStream_t st = ctx->stream;
 
@@ -639,6 +679,7 @@ int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, in
     if (rho_k < 1.0) rho_k = 1.0;
 
     WTP_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)(cap + 1), st));
+    WTP_HIP(ctx, hipMemsetAsync(dirty, 0, (size_t)cap + 64, st));
     // ctx->reuse_grid (one-shot, set by the relax session): keep the Grid of the previous build — origin, cell edge,
     // cell counts — and skip the bounding-box pass.  A point that has left the old box since is clamped into an
     // edge cell, which the kernels treat as unbounded outward, so the search stays exact.
@@ -651,13 +692,13 @@ int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, in
     }
     ctx->ncells_dev = &g->ncells;
     const int nb = grid_for(n_in, kThreads, 16384);
-    hipLaunchKernelGGL(cell_rank_kernel<T>, dim3(nb), dim3(kThreads), 0, st, in, n_in, g, cnt, cr, v_old, v_fixed_old);
+    hipLaunchKernelGGL(cell_rank_kernel<T>, dim3(nb), dim3(kThreads), 0, st, in, n_in, g, cnt, cr, dirty, v_old, v_fixed_old);
     hipLaunchKernelGGL(scan_reduce_kernel<T>, dim3(nscan), dim3(kThreads), 0, st, cnt, g, bs);
     hipLaunchKernelGGL(scan_top_kernel<T>, dim3(1), dim3(kThreads), 0, st, bs, g);
     hipLaunchKernelGGL(scan_apply_kernel<T>, dim3(nscan), dim3(kThreads), 0, st, cnt, bs, g, start);
-    hipLaunchKernelGGL(scatter_kernel<T>, dim3(nb), dim3(kThreads), 0, st, in, n_in, cr, start, out, v_old, v_fixed_old,
+    hipLaunchKernelGGL(scatter_kernel<T>, dim3(nb), dim3(kThreads), 0, st, in, n_in, cr, g, start, out, v_old, v_fixed_old,
                        v_shift);
-    hipLaunchKernelGGL(canon_kernel<T>, dim3(grid_for(cap, kThreads, 8192)), dim3(kThreads), 0, st, out, start, g);
+    hipLaunchKernelGGL(canon_kernel<T>, dim3(grid_for(cap, kThreads, 8192)), dim3(kThreads), 0, st, out, start, dirty, g);
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;
 }
