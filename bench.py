@@ -395,11 +395,23 @@ def main():
             ctx.gen_uniform_dev(wtp_amd.synth.SEED, first, n, 3, np.float32, t.data_ptr())
             return t
 
-        own_xyz, own_gid, cuts = sharded.uniform_shard(gen, rank, world, n_total, wtp_amd.synth.SEED, "cuda")
-        drv = sharded.ShardedRelax(sharded.GpuEngine(ctx, s, force, k, s / 2000, s / 20), dist, own_xyz, own_gid, cuts,
-                                   sharded.ghost_width(n_total, k, ctx_rho()),
-                                   comm_device="cpu" if rehearsal else None,
-                                   legacy=os.environ.get("WTP_SHARD_LEGACY") == "1")
+        slabs = os.environ.get("WTP_SHARD", "blocks") == "slabs"
+        if slabs:  # the round-1 decomposition: z-slabs, two neighbours
+            own_xyz, own_gid, cuts = sharded.uniform_shard(gen, rank, world, n_total, wtp_amd.synth.SEED, "cuda")
+            drv = sharded.ShardedRelax(sharded.GpuEngine(ctx, s, force, k, s / 2000, s / 20), dist, own_xyz, own_gid, cuts,
+                                       sharded.ghost_width(n_total, k, ctx_rho()),
+                                       comm_device="cpu" if rehearsal else None,
+                                       legacy=os.environ.get("WTP_SHARD_LEGACY") == "1")
+            shard_note = f"{world} z-slabs"
+        else:      # orthtree blocks (2 x 2 x 2 octants at 8 ranks), dimension-ordered ghost exchange
+            from whatsthepoint_jl_amd import blocks
+
+            grid = blocks.block_grid(world)
+            own_xyz, own_gid, cuts = blocks.uniform_block_shard(gen, rank, grid, n_total, "cuda")
+            drv = blocks.BlockShardedRelax(sharded.GpuEngine(ctx, s, force, k, s / 2000, s / 20), dist, own_xyz, own_gid,
+                                           grid, cuts, sharded.ghost_width(n_total, k, ctx_rho()),
+                                           comm_device="cpu" if rehearsal else None)
+            shard_note = f"{grid[0]} x {grid[1]} x {grid[2]} orthtree blocks (Morton rank order), dimension-ordered exchange"
 
         def run(iters):
             drv.run(iters)
@@ -481,7 +493,7 @@ def main():
                             + ("" if world == 1 or scaling == "weak" else
                                "; fixed total: the one-GPU point of this curve is --gpus 1 --points " + str(n_total)) + ")",
                 "points_per_gpu": n_local,
-                "sharding": "none" if world == 1 else f"{world} z-slabs, resident local sessions, ghost-layer exchange "
+                "sharding": "none" if world == 1 else f"{shard_note}, resident local sessions, ghost-layer exchange "
                                                      f"per iteration ({'gloo, ranks sharing one GPU (rehearsal)' if rehearsal else 'RCCL point-to-point'})",
             },
             "roofline": {

@@ -312,6 +312,10 @@ int wtp_relax_step_layers(wtp_ctx* ctx, int rebuild, wtp_step_stats* stats, int 
  * farther away than the nearer end of that range — so the caller can widen the layer and redo
  * the step (wtp_relax_revert).  axis < 0: unlimited (default).  */
 int wtp_relax_set_coverage(wtp_ctx* ctx, int axis, double lo, double hi);
+/* The same for a block decomposition (orthtree cells, 2 x 2 x 2 octants on 8 GPUs): the snapshot
+ * holds every point of the global cloud inside the box lo[a] <= coord[a] <= hi[a] (the rank's block plus the
+ * ghost layers received from its face, edge and corner neighbours; ends may be +-inf).  */
+int wtp_relax_set_coverage_box(wtp_ctx* ctx, const double lo[3], const double hi[3]);
 
 /* Replace the fixed head of the snapshot by n_fixed_new points (packed 4-vectors in device
  * memory, 4th component ignored).  Movable indices are unchanged; the next wtp_relax_step

@@ -1150,6 +1150,10 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
     a.cover_axis = r.cover_axis;
     a.cover_lo = (T)r.cover_lo;
     a.cover_hi = (T)r.cover_hi;
+    for (int ax = 0; ax < 3; ++ax) {
+        a.cover_lo3[ax] = (T)r.cover_lo3[ax];
+        a.cover_hi3[ax] = (T)r.cover_hi3[ax];
+    }
     a.uncovered = (int32_t*)ctx->fb_count.p + 8;
     WTP_HIP(ctx, hipMemsetAsync(ctx->fb_count.p, 0, 64, ctx->stream));
     a.used_brick = a.used_wave = a.used_generic = 0;
@@ -1752,6 +1756,19 @@ WTP_API int wtp_relax_set_coverage(wtp_ctx* ctx, int axis, double lo, double hi)
     r.cover_axis = axis < 0 ? -1 : axis;
     r.cover_lo = lo;
     r.cover_hi = hi;
+    return WTP_OK;
+}
+
+WTP_API int wtp_relax_set_coverage_box(wtp_ctx* ctx, const double lo[3], const double hi[3]) {
+    if (!ctx || !lo || !hi) return WTP_ERR_ARG;
+    RelaxState& r = ctx->relax;
+    if (!r.active) return fail(ctx, WTP_ERR_STATE, "wtp_relax_set_coverage_box before wtp_relax_init");
+    for (int ax = 0; ax < 3; ++ax) {
+        if (!(lo[ax] <= hi[ax])) return fail(ctx, WTP_ERR_ARG, "need lo <= hi on every axis");
+        r.cover_lo3[ax] = lo[ax];
+        r.cover_hi3[ax] = hi[ax];
+    }
+    r.cover_axis = 3;
     return WTP_OK;
 }
 

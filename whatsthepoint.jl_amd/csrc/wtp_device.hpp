@@ -165,6 +165,20 @@ __device__ inline T step_point(const SearchArgs<T>& a, T s, T xi, T yi, T zi, T 
 template <typename T>
 __device__ inline bool reaches_past_cover(const SearchArgs<T>& a, T qx, T qy, T qz, T need2) {
     if (a.cover_axis < 0) return false;
+    if (a.cover_axis == 3) { // a box (block decompositions): the nearest of its six faces decides
+        T d = qx - a.cover_lo3[0];
+        T e = a.cover_hi3[0] - qx;
+        d = e < d ? e : d;
+        e = qy - a.cover_lo3[1];
+        d = e < d ? e : d;
+        e = a.cover_hi3[1] - qy;
+        d = e < d ? e : d;
+        e = qz - a.cover_lo3[2];
+        d = e < d ? e : d;
+        e = a.cover_hi3[2] - qz;
+        d = e < d ? e : d;
+        return !(d > (T)0 && need2 <= d * d);
+    }
     const T v = a.cover_axis == 0 ? qx : (a.cover_axis == 1 ? qy : qz);
     const T dl = v - a.cover_lo, dh = a.cover_hi - v;
     const T d = dl < dh ? dl : dh;

@@ -122,8 +122,9 @@ template <typename T> struct SearchArgs {
     int32_t* nn_count;
     // sharded sessions: the snapshot is complete only for cover_lo <= coord[cover_axis] <= cover_hi;
     // queries whose neighbourhood reaches past that range are counted (wtp_relax_set_coverage)
-    int32_t cover_axis;        // -1: unlimited
+    int32_t cover_axis;        // -1: unlimited; 0..2: a slab along that axis; 3: the box cover_lo3 .. cover_hi3
     T cover_lo, cover_hi;
+    T cover_lo3[3], cover_hi3[3];
     int32_t* uncovered;
     // tunables
     T gamma_cap;               // initial filter radius cap, in cell edges
@@ -182,6 +183,7 @@ struct RelaxState {
     int64_t wall_nm = 0;      // movable points the wall arrays are sized for
     int cover_axis = -1;     // sharded session: snapshot complete for cover_lo <= coord[axis] <= cover_hi
     double cover_lo = 0, cover_hi = 0;
+    double cover_lo3[3] = {0, 0, 0}, cover_hi3[3] = {0, 0, 0}; // cover_axis == 3: a box (ends may be +-inf)
 };
 
 } // namespace wtp

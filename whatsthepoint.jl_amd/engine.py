@@ -442,6 +442,12 @@ class RelaxSession:
         self.n += int(n_fixed_new) - self.n_fixed
         self.n_fixed = int(n_fixed_new)
 
+    def set_coverage_box(self, lo3, hi3):
+        """Block decompositions: the snapshot is complete inside the box lo3 .. hi3 (ends may be +-inf)."""
+        lo = (C.c_double * 3)(*[float(v) for v in lo3])
+        hi = (C.c_double * 3)(*[float(v) for v in hi3])
+        L.check(self.ctx._h, self._lib.wtp_relax_set_coverage_box(self.ctx._h, lo, hi))
+
     def set_coverage(self, axis: int, lo: float = 0.0, hi: float = 0.0):
         """The snapshot is complete for lo <= coord[axis] <= hi (slab + ghost layers); sweeps report
         in n_uncovered the points whose neighbourhood reaches past it.  axis < 0: unlimited."""

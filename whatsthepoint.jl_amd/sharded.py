@@ -43,6 +43,7 @@ class GpuEngine:
         self.sess = None
         self.n_own = 0
         self.coverage = None  # (axis, lo, hi): coordinate range the local snapshot is complete for
+        self.coverage_box = None  # (lo3, hi3): the same as a box (block decompositions, blocks.py)
         self._lo = self._hi = None
         self._cap = 0
 
@@ -55,6 +56,13 @@ class GpuEngine:
                                    device_ptr=(owned_xyz.data_ptr(), self.n_own, 3, np.float32))
         if self.coverage:
             self.sess.set_coverage(*self.coverage)
+        if self.coverage_box:
+            self.sess.set_coverage_box(*self.coverage_box)
+
+    def set_coverage_box(self, lo3, hi3):
+        self.coverage_box = ([float(v) for v in lo3], [float(v) for v in hi3])
+        if self.sess is not None:
+            self.sess.set_coverage_box(*self.coverage_box)
 
     def set_coverage(self, axis: int, lo: float, hi: float):
         self.coverage = (int(axis), float(lo), float(hi))
