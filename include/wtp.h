@@ -305,6 +305,12 @@ int wtp_relax_layers_dev(wtp_ctx* ctx, int axis, double lo_in, double hi_in, dou
 int wtp_relax_step_layers(wtp_ctx* ctx, int rebuild, wtp_step_stats* stats, int axis, double lo_in, double hi_in,
                           double lo_out, double hi_out, void* d_lo4, void* d_hi4, int64_t cap, int64_t counts[4]);
 
+/* The same for a block decomposition: layers along up to three axes (bit a of axes_mask set), all with the one
+ * read-back.  counts[4*a .. 4*a+3] as above; d_lo4[a] / d_hi4[a] hold `cap` rows each.  */
+int wtp_relax_step_layers3(wtp_ctx* ctx, int rebuild, wtp_step_stats* stats, int axes_mask, const double lo_in[3],
+                           const double hi_in[3], const double lo_out[3], const double hi_out[3], void* const d_lo4[3],
+                           void* const d_hi4[3], int64_t cap, int64_t counts[12]);
+
 /* Coverage of a sharded session: the caller guarantees that the snapshot holds every point of
  * the global cloud with lo <= coord[axis] <= hi (its slab plus the ghost layers; an end may be
  * +-inf).  A sweep then counts in stats.n_uncovered the movable points whose answer needs more:

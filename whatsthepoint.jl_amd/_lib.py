@@ -89,6 +89,9 @@ SIGNATURES = {
     "wtp_relax_layers_dev": (_i, [_vp, _i, _d, _d, _d, _d, _vp, _vp, _i64, C.POINTER(_i64)]),
     "wtp_relax_set_fixed_dev": (_i, [_vp, _vp, _i64]),
     "wtp_relax_step_layers": (_i, [_vp, _i, C.POINTER(StepStats), _i, _d, _d, _d, _d, _vp, _vp, _i64, C.POINTER(_i64)]),
+    "wtp_relax_step_layers3": (_i, [_vp, _i, C.POINTER(StepStats), _i, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_vp), C.POINTER(_vp), _i64,
+                                    C.POINTER(_i64)]),
     "wtp_relax_set_coverage": (_i, [_vp, _i, _d, _d]),
     "wtp_relax_set_coverage_box": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "wtp_timers_get": (_i, [_vp, C.POINTER(_d)]),

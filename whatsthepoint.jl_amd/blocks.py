@@ -106,6 +106,7 @@ class BlockShardedRelax:
         self.widened = 0
         self.history = []
         self.last_local_points = int(owned_xyz.shape[0])
+        self._next = None  # (planes, layers, strays) extracted together with the previous sweep
 
     # ---- geometry -----------------------------------------------------------------------------------------
     def _bounds(self, a: int):
@@ -186,15 +187,20 @@ class BlockShardedRelax:
         dt = torch.float32
         # strays: an owned point more than `margin` past a face of the block triggers the hand-over
         xyz = None
-        layers = {}
-        n_stray = 0
+        planes = {}
         for a in range(3):
-            if self.p[a] == 1:
-                continue
-            lo, hi = self._bounds(a)
-            lo_rows, hi_rows, s = eng.layers(a, lo + w_eff, hi - w_eff, lo - self.margin, hi + self.margin)
-            layers[a] = (lo_rows, hi_rows)
-            n_stray += s
+            if self.p[a] > 1:
+                lo, hi = self._bounds(a)
+                planes[a] = (lo + w_eff, hi - w_eff, lo - self.margin, hi + self.margin)
+        if self._next is not None and self._next[0] == planes:
+            _, layers, n_stray = self._next  # came home with the previous sweep's statistics
+        else:
+            layers, n_stray = {}, 0
+            for a, pl in planes.items():
+                lo_rows, hi_rows, s = eng.layers(a, *pl)
+                layers[a] = (lo_rows.clone(), hi_rows.clone())  # (the engine reuses one pair of buffers per call)
+                n_stray += s
+        self._next = None
         migrate = n_stray > 0
         mig_x = torch.zeros((0, 3), dtype=dt, device=self.dev)   # migrants in transit through this rank (or arriving)
         mig_g = torch.zeros((0,), dtype=torch.int64, device=self.dev)
@@ -266,7 +272,11 @@ class BlockShardedRelax:
         eng.set_ghosts(self._rows4(pool))
         n_own = int(self.gid.shape[0])
         self.last_local_points = n_own + n_ghost
-        st = eng.step()
+        if hasattr(eng, "step_and_layers3"):
+            st, nl, ns = eng.step_and_layers3(planes)
+            self._next = (planes, nl, ns) if nl is not None else None
+        else:
+            st = eng.step()
         mine = torch.tensor([st["max_force"], st["sum_u"], st["sum_u2"], float(st["n_move"]),
                              float(st.get("n_uncovered", 0))], dtype=torch.float64, device=self.cdev)
         allv = [torch.zeros_like(mine) for _ in range(self.world)]
@@ -279,6 +289,7 @@ class BlockShardedRelax:
             if attempt >= 4 or not hasattr(eng, "revert"):
                 raise RuntimeError(f"{out['n_uncovered']} queries reach past the ghost layer (w={self.w:g})")
             eng.revert()
+            self._next = None
             self.w *= 1.5
             self.widened += 1
             self._set_coverage()

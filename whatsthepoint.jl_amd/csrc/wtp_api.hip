@@ -1579,16 +1579,18 @@ WTP_API int wtp_set_stream(wtp_ctx* ctx, void* hip_stream, int external) {
 
 // launches the two layer kernels on the current P; *d_tot_out = device address of the four counts
 static int enqueue_layers(wtp_ctx* ctx, int axis, double lo_in, double hi_in, double lo_out, double hi_out, void* d_lo4,
-                          void* d_hi4, int64_t cap, int32_t** d_tot_out) {
+                          void* d_hi4, int64_t cap, int32_t** d_tot_out, int slot = 0) {
     RelaxState& r = ctx->relax;
     if (axis < 0 || axis >= r.dim) return fail(ctx, WTP_ERR_ARG, "axis must be in [0, dim)");
     if (cap < 0 || (cap > 0 && (!d_lo4 || !d_hi4))) return fail(ctx, WTP_ERR_ARG, "layer buffers are NULL");
     if (int rcf = flush_pending(ctx)) return rcf;
     int rc;
     const int nblk = layer_blocks(r.n);
-    if ((rc = ensure(ctx, ctx->scratch, 64 + sizeof(int2) * (size_t)nblk))) return rc;
-    int32_t* d_tot = (int32_t*)ctx->scratch.p;
-    int2* d_blk = (int2*)((char*)ctx->scratch.p + 64);
+    // (three regions: wtp_relax_step_layers3 keeps the layers of all three axes in flight)
+    const size_t region = (64 + sizeof(int2) * (size_t)nblk + 63) / 64 * 64;
+    if ((rc = ensure(ctx, ctx->scratch, 3 * region))) return rc;
+    int32_t* d_tot = (int32_t*)((char*)ctx->scratch.p + (size_t)slot * region);
+    int2* d_blk = (int2*)((char*)d_tot + 64);
     // P is in the slot order of the last rebuild's grid (and nobody moved farther than one spacing,
     // src/repel.jl:286-289) whenever a sweep produced it: then only the boundary cell layers are scanned
     const bool slot_ordered = r.have_tree && r.have_point_data && axis == r.dim - 1 && r.bufP != r.bufS &&
@@ -1756,6 +1758,41 @@ WTP_API int wtp_relax_set_coverage(wtp_ctx* ctx, int axis, double lo, double hi)
     r.cover_axis = axis < 0 ? -1 : axis;
     r.cover_lo = lo;
     r.cover_hi = hi;
+    return WTP_OK;
+}
+
+// wtp_relax_step_layers for a block decomposition: the layers of up to three axes (bit a of axes_mask) come home
+// with the statistics, one read-back and one synchronisation for everything.  counts[4*a .. 4*a+3] as in
+// wtp_relax_layers_dev; d_lo4[a] / d_hi4[a] each hold `cap` rows.
+WTP_API int wtp_relax_step_layers3(wtp_ctx* ctx, int rebuild, wtp_step_stats* stats, int axes_mask, const double lo_in[3],
+                                   const double hi_in[3], const double lo_out[3], const double hi_out[3], void* const d_lo4[3],
+                                   void* const d_hi4[3], int64_t cap, int64_t counts[12]) {
+    if (!ctx) return WTP_ERR_ARG;
+    if (!ctx->relax.active) return fail(ctx, WTP_ERR_STATE, "wtp_relax_step_layers3 before wtp_relax_init");
+    if (!stats || !counts || !lo_in || !hi_in || !lo_out || !hi_out || !d_lo4 || !d_hi4)
+        return fail(ctx, WTP_ERR_ARG, "NULL argument");
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, ctx->stats, sizeof(wtp_step_stats)))) return rc;
+    if ((rc = relax_step_any(ctx, rebuild, (wtp_step_stats*)ctx->stats.p))) return rc;
+    int32_t* d_tot[3] = {nullptr, nullptr, nullptr};
+    for (int ax = 0; ax < 3; ++ax)
+        if (axes_mask & (1 << ax))
+            if ((rc = enqueue_layers(ctx, ax, lo_in[ax], hi_in[ax], lo_out[ax], hi_out[ax], d_lo4[ax], d_hi4[ax], cap,
+                                     &d_tot[ax], ax)))
+                return rc;
+    const size_t off = (sizeof(wtp_step_stats) + 63) / 64 * 64;
+    if ((rc = ensure_pinned(ctx, off + 3 * 64))) return rc;
+    WTP_HIP(ctx, hipMemcpyAsync(ctx->host_pinned, ctx->stats.p, sizeof(wtp_step_stats), hipMemcpyDeviceToHost, ctx->stream));
+    for (int ax = 0; ax < 3; ++ax)
+        if (d_tot[ax])
+            WTP_HIP(ctx, hipMemcpyAsync((char*)ctx->host_pinned + off + 64 * ax, d_tot[ax], 4 * sizeof(int32_t),
+                                        hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = sync(ctx))) return rc;
+    memcpy(stats, ctx->host_pinned, sizeof(wtp_step_stats));
+    for (int ax = 0; ax < 3; ++ax)
+        for (int j = 0; j < 4; ++j)
+            counts[4 * ax + j] = d_tot[ax] ? ((const int32_t*)((const char*)ctx->host_pinned + off + 64 * ax))[j] : 0;
     return WTP_OK;
 }
 

@@ -434,6 +434,18 @@ class RelaxSession:
         L.check(self.ctx._h, rc)
         return _stats_dict(st), tuple(int(c) for c in cnt)
 
+    def step_layers3(self, rebuild, axes_mask, lo_in3, hi_in3, lo_out3, hi_out3, d_lo_ptrs, d_hi_ptrs, cap):
+        """step_layers along up to three axes (bit a of axes_mask), one synchronisation for everything:
+        returns (stats, [(n_lo, n_hi, n_stray_lo, n_stray_hi)] * 3)."""
+        st = L.StepStats()
+        cnt = (C.c_int64 * 12)()
+        d3 = lambda v: (C.c_double * 3)(*[float(x) for x in v])
+        p3 = lambda v: (C.c_void_p * 3)(*[C.c_void_p(int(x)) for x in v])
+        rc = self._lib.wtp_relax_step_layers3(self.ctx._h, int(bool(rebuild)), C.byref(st), int(axes_mask), d3(lo_in3),
+                                              d3(hi_in3), d3(lo_out3), d3(hi_out3), p3(d_lo_ptrs), p3(d_hi_ptrs), int(cap), cnt)
+        L.check(self.ctx._h, rc)
+        return _stats_dict(st), [tuple(int(cnt[4 * a + j]) for j in range(4)) for a in range(3)]
+
     def set_fixed_dev(self, d_fixed4_ptr: int, n_fixed_new: int):
         """Replace the fixed head of the snapshot by n_fixed_new packed 4-vectors in device memory."""
         rc = self._lib.wtp_relax_set_fixed_dev(self.ctx._h, C.c_void_p(d_fixed4_ptr) if n_fixed_new else None,

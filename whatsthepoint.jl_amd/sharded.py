@@ -107,6 +107,32 @@ class GpuEngine:
             return st, None
         return st, (self._lo[:n_lo], self._hi[:n_hi], s_lo + s_hi)
 
+    def step_and_layers3(self, planes):
+        """Block decompositions: one sweep and the next iteration's layers along every sharded axis, one
+        synchronisation.  planes = {axis: (lo_in, hi_in, lo_out, hi_out)}.  Returns (stats, {axis: (lo rows, hi rows)},
+        strays) or (stats, None, 0) when a layer outgrew its buffer."""
+        if not hasattr(self, "_l3") or self._l3_cap == 0:
+            self._grow3(max(4096, self.n_own // 8))
+        inf = float("inf")
+        lo_in, hi_in, lo_out, hi_out = [-inf] * 3, [inf] * 3, [-inf] * 3, [inf] * 3
+        mask = 0
+        for a, (li, hi_, lo_, ho) in planes.items():
+            lo_in[a], hi_in[a], lo_out[a], hi_out[a] = li, hi_, lo_, ho
+            mask |= 1 << a
+        st, cnt = self.sess.step_layers3(True, mask, lo_in, hi_in, lo_out, hi_out, [t.data_ptr() for t in self._l3[0]],
+                                         [t.data_ptr() for t in self._l3[1]], self._l3_cap)
+        need = max(max(c[0], c[1]) for c in cnt)
+        if need > self._l3_cap:
+            self._grow3(int(1.25 * need) + 1024)
+            return st, None, 0
+        out = {a: (self._l3[0][a][: cnt[a][0]], self._l3[1][a][: cnt[a][1]]) for a in planes}
+        return st, out, sum(cnt[a][2] + cnt[a][3] for a in planes)
+
+    def _grow3(self, cap):
+        self._l3_cap = int(cap)
+        mk = lambda: [torch.empty((self._l3_cap, 4), dtype=torch.int32, device=self.dev) for _ in range(3)]
+        self._l3 = (mk(), mk())
+
     def positions(self) -> torch.Tensor:
         out = torch.empty((self.n_own, 3), dtype=torch.float32, device=self.dev)
         if self.n_own:
