@@ -169,6 +169,16 @@ int wtp_relax_step(wtp_ctx* ctx, int rebuild, wtp_step_stats* stats);
 int wtp_relax_run(wtp_ctx* ctx, int n_iters, int rebuild_every, double* conv_out,
                   wtp_step_stats* last);
 
+/* The loop of `_relax!` WITH its stop rules (src/repel.jl:305-334), evaluated on the device after every sweep in the
+ * reference's order: cv_target (positions are then reverted to p_old, :314), stall_after on the CV of d_NN / s
+ * (:316-326), tol on max |F| s (:329-332).  Sweeps are enqueued in batches of 16 without any host round trip; once a
+ * rule fires the rest of the batch does nothing, so the session ends in exactly the state of the reference's last
+ * iteration.  conv_out[0 .. *n_done) = max |F| s per sweep; *reason: 0 max_iters reached, 1 tol, 2 cv_target, 3 stall.
+ * Not for sessions with the octree wall rule (wtp_relax_set_wall), kicks, traces or a caller-evaluated spacing:
+ * those need the host between two sweeps (wtp_relax_step).  */
+int wtp_relax_run_until(wtp_ctx* ctx, int max_iters, int rebuild_every, double tol, int stall_after, double cv_target,
+                        double* conv_out, int* n_done, int* reason, wtp_step_stats* last);
+
 /* Current movable points, (n - n_fixed) x dim of dtype, snapshot order. */
 int wtp_relax_get(wtp_ctx* ctx, void* xyz_out);
 /* Same into device memory on the context's GPU (sharded driver: no host round trip). */

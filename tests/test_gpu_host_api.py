@@ -164,3 +164,55 @@ def test_radius_offsets_on_device_equals_two_phase(ctx, O, wtp):
         ooff, oidx = O.radius(x, r)
         assert np.array_equal(off, off2) and np.array_equal(idx, idx2)
         assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("rules", [dict(tol=1e-6, stall_after=6, cv_target=0.0), dict(tol=0.05, stall_after=0, cv_target=0.0),
+                                   dict(tol=1e-9, stall_after=0, cv_target=10.0), dict(tol=0.0, stall_after=0, cv_target=0.0)])
+def test_stop_rules_on_the_device_equal_the_host_loop(ctx, wtp, dtype, rules):
+    """wtp_relax_run_until (stop rules of src/repel.jl:305-334 evaluated on the device, sweeps enqueued in batches)
+    against one wtp_relax_step per iteration with the rules applied on the host: the same number of iterations,
+    the same convergence history and the same final positions, bit for bit — the sweeps enqueued behind the
+    stopping one must not have touched the state."""
+    import math
+
+    n, k, max_iters = 30000, 21, 40
+    x = wtp.synth.uniform(n, 3, dtype, 11)
+    s = float(n) ** (-1.0 / 3.0)
+    force = dict(kind=2, beta=0.2, u0=1.0, gamma=3.0)
+    with ctx.relax(x, 2000, s, force, k, s / 2000, s / 20) as t:
+        conv_d, reason, st = t.run_until(max_iters, 2, rules["tol"], rules["stall_after"], rules["cv_target"])
+        p_d = t.positions()
+        pd_d = t.point_data()
+    conv_h, best, last_impr, why = [], math.inf, 0, 0
+    with ctx.relax(x, 2000, s, force, k, s / 2000, s / 20) as t:
+        i = 1
+        while i <= max_iters:
+            st = t.step((i - 1) % 2 == 0)
+            conv_h.append(st["max_force"])
+            if (rules["stall_after"] > 0 or rules["cv_target"] > 0) and st["n_move"] > 0:
+                mu = st["sum_u"] / st["n_move"]
+                cv = math.sqrt(max(st["sum_u2"] / st["n_move"] - mu * mu, 0.0)) / mu
+                if rules["cv_target"] > 0 and cv <= rules["cv_target"]:
+                    t.revert()
+                    why = 2
+                    break
+                if rules["stall_after"] > 0:
+                    if cv < best * (1 - 1.0e-3):
+                        best, last_impr = cv, i
+                    elif i - last_impr >= rules["stall_after"]:
+                        why = 3
+                        break
+            if conv_h[-1] < rules["tol"]:
+                why = 1
+                break
+            i += 1
+        p_h = t.positions()
+    assert reason == why and len(conv_d) == len(conv_h)
+    assert np.array_equal(conv_d, np.asarray(conv_h))
+    assert np.array_equal(p_d, p_h)
+    if rules["cv_target"] > 0:
+        assert len(conv_d) == 1 and np.array_equal(p_d, x[2000:])       # test/repel.jl:282-290: stopped after one, unchanged
+    if rules["tol"] == 0.0 and rules["stall_after"] == 0:
+        assert len(conv_d) == max_iters and reason == 0
+    assert np.isfinite(pd_d["forces"]).all()

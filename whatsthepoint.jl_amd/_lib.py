@@ -62,6 +62,7 @@ SIGNATURES = {
     "wtp_relax_init_dev": (_i, [_vp, _vp, _i64, _i64, _i, _i, C.POINTER(SpacingDesc), C.POINTER(ForceDesc), _i, _d, _d]),
     "wtp_relax_step": (_i, [_vp, _i, C.POINTER(StepStats)]),
     "wtp_relax_run": (_i, [_vp, _i, _i, _vp, C.POINTER(StepStats)]),
+    "wtp_relax_run_until": (_i, [_vp, _i, _i, _d, _i, _d, _vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(StepStats)]),
     "wtp_relax_get": (_i, [_vp, _vp]),
     "wtp_relax_get_dev": (_i, [_vp, _vp]),
     "wtp_relax_get_point_data": (_i, [_vp, _vp, _vp, _vp]),

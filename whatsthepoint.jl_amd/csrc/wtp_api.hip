@@ -1136,6 +1136,7 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
     // one 64-byte counter block, cleared once per sweep: [0] hand-backs of the brick kernel,
     // [4] of the wave kernel, [8] uncovered queries
     a.fb2_count = (int32_t*)ctx->fb_count.p + 4;
+    a.stop = ctx->stop_dev;
     a.nn_list = nullptr;
     a.nn_count = (int32_t*)ctx->fb_count.p + 2;
     if (r.cs_sweep && r.cs2_bx > 0) {
@@ -1225,6 +1226,117 @@ WTP_API int wtp_relax_run(wtp_ctx* ctx, int n_iters, int rebuild_every, double* 
         return WTP_OK;
     }
     return sync(ctx);
+}
+
+// ---- stop rules on the device (src/repel.jl:305-334) -----------------------------------------------------------
+// After every sweep of a batch one thread applies the reference's rules, in the reference's order, to that sweep's
+// statistics: cv_target (the caller then reverts p to p_old), the stall counter on the CV of d_NN / s, the tolerance
+// on max |F| s.  Once a rule fires, every kernel of the later iterations of the batch that would touch the session's
+// state returns at once (SearchArgs::stop / ctx->stop_dev), so the state is that of the stopping iteration.
+struct StopState {
+    int32_t stopped, reason, n_done, last_impr;
+    double best_cv;
+};
+__global__ void stop_rules_kernel(const wtp_step_stats* __restrict__ st, StopState* __restrict__ s, int iter1, double tol,
+                                  int stall_after, double cv_target) {
+    if (s->stopped) return;
+    s->n_done = iter1;
+    const double conv = st->max_force;
+    if ((stall_after > 0 || cv_target > 0) && st->n_move > 0) {
+        const double n = (double)st->n_move, mu = st->sum_u / n;
+        const double var = st->sum_u2 / n - mu * mu;
+        const double cv = sqrt(var > 0.0 ? var : 0.0) / mu; // _dnn_cv, src/repel.jl:374-386
+        if (cv_target > 0 && cv <= cv_target) {
+            s->stopped = 1;
+            s->reason = 2;
+            return;
+        }
+        if (stall_after > 0) {
+            if (cv < s->best_cv * (1 - 1.0e-3)) {
+                s->best_cv = cv;
+                s->last_impr = iter1;
+            } else if (iter1 - s->last_impr >= stall_after) {
+                s->stopped = 1;
+                s->reason = 3;
+                return;
+            }
+        }
+    }
+    if (conv < tol) {
+        s->stopped = 1;
+        s->reason = 1;
+    }
+}
+
+WTP_API int wtp_relax_run_until(wtp_ctx* ctx, int max_iters, int rebuild_every, double tol, int stall_after,
+                                double cv_target, double* conv_out, int* n_done_out, int* reason_out,
+                                wtp_step_stats* last) {
+    if (!ctx) return WTP_ERR_ARG;
+    RelaxState& r = ctx->relax;
+    if (!r.active) return fail(ctx, WTP_ERR_STATE, "wtp_relax_run_until before wtp_relax_init");
+    if (rebuild_every < 1) return fail(ctx, WTP_ERR_ARG, "rebuild_every must be >= 1"); // src/repel.jl:74
+    if (max_iters < 0) return fail(ctx, WTP_ERR_ARG, "max_iters must be >= 0");
+    if (r.wall_active) return fail(ctx, WTP_ERR_STATE, "wtp_relax_run_until: the octree wall rule steps through wtp_relax_step");
+    if (n_done_out) *n_done_out = 0;
+    if (reason_out) *reason_out = 0;
+    if (max_iters == 0) return WTP_OK;
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, ctx->stats, sizeof(wtp_step_stats) * (size_t)max_iters))) return rc;
+    if ((rc = ensure(ctx, ctx->stop_state, 64))) return rc;
+    if ((rc = ensure_pinned(ctx, 64 + sizeof(wtp_step_stats) * (size_t)max_iters))) return rc;
+    StopState h0{};
+    h0.best_cv = __builtin_huge_val(); // typemax(U), src/repel.jl:238
+    memcpy(ctx->host_pinned, &h0, sizeof(h0));
+    WTP_HIP(ctx, hipMemcpyAsync(ctx->stop_state.p, ctx->host_pinned, sizeof(h0), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = sync(ctx))) return rc; // (the pinned block is reused for the read-backs below)
+    wtp_step_stats* d = (wtp_step_stats*)ctx->stats.p;
+    StopState* ds = (StopState*)ctx->stop_state.p;
+    const int kBatch = 16; // sweeps enqueued between two looks at the stop state
+    std::vector<RelaxState> hist;
+    hist.reserve((size_t)kBatch);
+    int done = 0, reason = 0;
+    ctx->stop_dev = &ds->stopped;
+    for (int i0 = 0; i0 < max_iters && !reason; i0 += kBatch) {
+        const int i1 = i0 + kBatch < max_iters ? i0 + kBatch : max_iters;
+        hist.clear();
+        for (int i = i0; i < i1; ++i) {
+            if ((rc = relax_step_any(ctx, (i % rebuild_every) == 0, d + i))) {
+                ctx->stop_dev = nullptr;
+                return rc;
+            }
+            hist.push_back(r); // what the host believes after this sweep (buffer roles, grid age, ...)
+            hipLaunchKernelGGL(stop_rules_kernel, dim3(1), dim3(1), 0, ctx->stream, d + i, ds, i + 1, tol, stall_after, cv_target);
+        }
+        WTP_HIP(ctx, hipMemcpyAsync(ctx->host_pinned, ds, sizeof(StopState), hipMemcpyDeviceToHost, ctx->stream));
+        if ((rc = sync(ctx))) {
+            ctx->stop_dev = nullptr;
+            return rc;
+        }
+        StopState hs;
+        memcpy(&hs, ctx->host_pinned, sizeof(hs));
+        done = hs.n_done;
+        if (hs.stopped) {
+            reason = hs.reason;
+            r = hist[(size_t)(done - 1 - i0)]; // the sweeps after the stop did nothing: forget that they were enqueued
+        }
+    }
+    ctx->stop_dev = nullptr;
+    if (reason == 2) { // cv_target: p .= p_old (src/repel.jl:314)
+        if ((rc = wtp_relax_revert(ctx))) return rc;
+    }
+    if (conv_out || last) {
+        WTP_HIP(ctx, hipMemcpyAsync(ctx->host_pinned, d, sizeof(wtp_step_stats) * (size_t)done, hipMemcpyDeviceToHost,
+                                    ctx->stream));
+        if ((rc = sync(ctx))) return rc;
+        const wtp_step_stats* hst = (const wtp_step_stats*)ctx->host_pinned;
+        if (conv_out)
+            for (int i = 0; i < done; ++i) conv_out[i] = hst[i].max_force;
+        if (last && done > 0) *last = hst[done - 1];
+    }
+    if (n_done_out) *n_done_out = done;
+    if (reason_out) *reason_out = reason;
+    return WTP_OK;
 }
 
 WTP_API int wtp_relax_get(wtp_ctx* ctx, void* xyz_out) {

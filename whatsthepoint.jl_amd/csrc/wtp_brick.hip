@@ -234,6 +234,7 @@ struct SpecForce {
 
 template <int MODE, int KT, int CS>
 __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(SearchArgs<float> a, int hcap) {
+    if (a.stop && *a.stop) return; // wtp_relax_run_until: a stop rule fired earlier in this batch
     constexpr int nb = CS ? 32 : NB; // ring rows: the compact-support sweep keeps only the support
     // candidates per scan step: the compact-support grid has short runs (3 cells x ~3.5 points), where
     // steps of 8 would spend half their slots past the run end

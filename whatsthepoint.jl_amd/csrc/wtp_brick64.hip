@@ -62,6 +62,7 @@ static __host__ __device__ size_t b64_smem_bytes(int hcap, size_t ptsz) {
 
 template <typename T>
 __global__ __launch_bounds__(kB64Threads, 2) void brick_cs_kernel(SearchArgs<T> a, int hcap) {
+    if (a.stop && *a.stop) return; // wtp_relax_run_until: a stop rule fired earlier in this batch
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Pt<T>* pts = reinterpret_cast<Pt<T>*>(smem_raw);
     uint16_t* ring_all = reinterpret_cast<uint16_t*>(smem_raw + (size_t)(hcap + kB64SU) * sizeof(Pt<T>));

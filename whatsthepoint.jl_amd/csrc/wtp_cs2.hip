@@ -131,6 +131,7 @@ static size_t cs2_smem_bytes(int hcap) {
 }
 
 __global__ __launch_bounds__(kCsThreads, 4) void cs2_kernel(SearchArgs<float> a, int hcap, int BX) {
+    if (a.stop && *a.stop) return; // wtp_relax_run_until: a stop rule fired earlier in this batch
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* pts = reinterpret_cast<float4*>(smem_raw);
     const uint32_t ring_off = (uint32_t)hcap * 16u + (uint32_t)kCsPadBytes;
@@ -645,6 +646,7 @@ constexpr int kNnFixBlocks = 512;
 constexpr int kNnFixThreads = 1024; // 16 waves per block, one query per wave at a time: the search is a chain of
                                     // dependent global loads, so it wants many waves in flight, not many lanes per query
 __global__ __launch_bounds__(kNnFixThreads, 8) void cs2_nnfix_kernel(SearchArgs<float> a, int part_base) {
+    if (a.stop && *a.stop) return; // wtp_relax_run_until: a stop rule fired earlier in this batch
     __shared__ Acc sacc[kNnFixThreads / 64];
     const Grid<float> g = *a.grid;
     const int n = *a.nn_count;

@@ -16,6 +16,7 @@ template <typename T, int MODE> // MODE 0: topology rows, 1: relax sweep
 __global__ __launch_bounds__(kThreads) void generic_kernel(SearchArgs<T> a, const int32_t* __restrict__ list,
                                                            const int32_t* __restrict__ list_count,
                                                            int all, int part_base) {
+    if (a.stop && *a.stop) return; // wtp_relax_run_until: a stop rule fired earlier in this batch
     __shared__ Acc sm_acc[kThreads / 64];
     const Grid<T> g = *a.grid;
     const int nq = all ? a.n : *list_count;

@@ -86,7 +86,8 @@ __global__ void bbox_kernel(const Pt<T>* __restrict__ pts, int64_t n, T* __restr
 template <typename T>
 __global__ void grid_setup_kernel(const T* __restrict__ part, int nparts, Grid<T>* __restrict__ g,
                                   int64_t npts, int dim, double rho_k, double radius, double min_cell, int cell_cap,
-                                  double cell_scale, const double* __restrict__ box) {
+                                  double cell_scale, const double* __restrict__ box, const int32_t* __restrict__ stop) {
+    if (stop && *stop) return; // a stop rule fired earlier in this batch: the state of that iteration stays as it is
     // one wave: lanes stride over the per-block partials, shuffle-reduce, lane 0 does the setup
     double mn[3], mx[3];
     for (int a = 0; a < 3; ++a) {
@@ -280,8 +281,10 @@ __global__ void scan_top_kernel(int32_t* __restrict__ block_sums, const Grid<T>*
 
 template <typename T>
 __global__ void scan_apply_kernel(const int32_t* __restrict__ cnt, const int32_t* __restrict__ block_sums,
-                                  const Grid<T>* __restrict__ gp, int32_t* __restrict__ cell_start) {
+                                  const Grid<T>* __restrict__ gp, int32_t* __restrict__ cell_start,
+                                  const int32_t* __restrict__ stop) {
     __shared__ int sm[kThreads / 64 + 1];
+    if (stop && *stop) return;
     int ncells = gp->ncells;
     int base = blockIdx.x * kScanTile;
     if (base >= ncells) return;
@@ -337,7 +340,9 @@ __global__ void scan_apply_kernel(const int32_t* __restrict__ cnt, const int32_t
 template <typename T>
 __global__ void scatter_kernel(const Pt<T>* __restrict__ pts, int64_t n, const int32_t* __restrict__ cell_rank,
                                const Grid<T>* __restrict__ gp, const int32_t* __restrict__ cell_start,
-                               Pt<T>* __restrict__ out, int64_t v_old, int32_t v_fixed_old, int32_t v_id_shift) {
+                               Pt<T>* __restrict__ out, int64_t v_old, int32_t v_fixed_old, int32_t v_id_shift,
+                               const int32_t* __restrict__ stop) {
+    if (stop && *stop) return;
     const Grid<T> g = *gp;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -370,7 +375,8 @@ template <typename T>
 __global__ __launch_bounds__(kThreads) void canon_kernel(Pt<T>* __restrict__ pts,
                                                          const int32_t* __restrict__ cell_start,
                                                          const uint8_t* __restrict__ dirty,
-                                                         const Grid<T>* __restrict__ gp) {
+                                                         const Grid<T>* __restrict__ gp, const int32_t* __restrict__ stop) {
+    if (stop && *stop) return;
     const int ncells = gp->ncells;
     for (int cell = blockIdx.x * kThreads + threadIdx.x; cell < ncells; cell += gridDim.x * kThreads) {
         if (!dirty[cell]) continue; // filled by one run of the input: in order already
@@ -688,17 +694,18 @@ int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, in
     if (!reuse) {
         hipLaunchKernelGGL(bbox_kernel<T>, dim3(nbb), dim3(kThreads), 0, st, in, n_in, part, v_old, v_fixed_old);
         hipLaunchKernelGGL(grid_setup_kernel<T>, dim3(1), dim3(64), 0, st, part, nbb, g, n, dim, rho_k, radius, min_cell,
-                           cap, cell_scale, ctx->box_active ? (const double*)ctx->box_dev.p : (const double*)nullptr);
+                           cap, cell_scale, ctx->box_active ? (const double*)ctx->box_dev.p : (const double*)nullptr, ctx->stop_dev);
     }
     ctx->ncells_dev = &g->ncells;
     const int nb = grid_for(n_in, kThreads, 16384);
     hipLaunchKernelGGL(cell_rank_kernel<T>, dim3(nb), dim3(kThreads), 0, st, in, n_in, g, cnt, cr, dirty, v_old, v_fixed_old);
     hipLaunchKernelGGL(scan_reduce_kernel<T>, dim3(nscan), dim3(kThreads), 0, st, cnt, g, bs);
     hipLaunchKernelGGL(scan_top_kernel<T>, dim3(1), dim3(kThreads), 0, st, bs, g);
-    hipLaunchKernelGGL(scan_apply_kernel<T>, dim3(nscan), dim3(kThreads), 0, st, cnt, bs, g, start);
+    hipLaunchKernelGGL(scan_apply_kernel<T>, dim3(nscan), dim3(kThreads), 0, st, cnt, bs, g, start, ctx->stop_dev);
     hipLaunchKernelGGL(scatter_kernel<T>, dim3(nb), dim3(kThreads), 0, st, in, n_in, cr, g, start, out, v_old, v_fixed_old,
-                       v_shift);
-    hipLaunchKernelGGL(canon_kernel<T>, dim3(grid_for(cap, kThreads, 8192)), dim3(kThreads), 0, st, out, start, dirty, g);
+                       v_shift, ctx->stop_dev);
+    hipLaunchKernelGGL(canon_kernel<T>, dim3(grid_for(cap, kThreads, 8192)), dim3(kThreads), 0, st, out, start, dirty, g,
+                       ctx->stop_dev);
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;
 }

@@ -120,6 +120,7 @@ template <typename T> struct SearchArgs {
     int32_t* fb2_count;
     int32_t* nn_list;          // round-2 sweep: queries whose nearest neighbour the follow-up kernel still has to find
     int32_t* nn_count;
+    const int32_t* stop;       // wtp_relax_run_until: non-zero once a stop rule has fired; later sweeps of the batch do nothing
     // sharded sessions: the snapshot is complete only for cover_lo <= coord[cover_axis] <= cover_hi;
     // queries whose neighbourhood reaches past that range are counted (wtp_relax_set_coverage)
     int32_t cover_axis;        // -1: unlimited; 0..2: a slab along that axis; 3: the box cover_lo3 .. cover_hi3
@@ -227,6 +228,8 @@ struct wtp_ctx {
     wtp::DevBuf cand_idx, cand_dist, f32_pts; // fp64 topology: fp32 candidate lists and the float copy of the cloud
     wtp::DevBuf forces, nn_dist, nn_id, spacing_pp;
     wtp::DevBuf partials, stats, fb_list, fb_count, fb2_list, fb2_count, nn_list;
+    wtp::DevBuf stop_state;           // wtp_relax_run_until: {stopped, reason, n_done, last_impr, best_cv} on the device
+    const int32_t* stop_dev = nullptr; // its first word while such a run is enqueued, else NULL (kernels then never look)
     wtp::DevBuf scratch;       // misc (relax_get staging, radius rows)
     wtp::DevBuf diag;          // diagnostic builds only
     wtp::DevBuf ins_in, ins_elems, ins_partial, ins_out; // isinside filter

@@ -213,8 +213,10 @@ __global__ void spacing_eval_kernel(const T* __restrict__ xyz, int64_t n, int di
 template <typename T>
 __global__ void spacing_session_kernel(const Pt<T>* __restrict__ pts, int64_t n, int32_t first_id,
                                        const KdNode<T>* __restrict__ nodes, int32_t m, SpacingLaw<T> law,
-                                       T* __restrict__ spacing_pp, int32_t* __restrict__ hint) {
+                                       T* __restrict__ spacing_pp, int32_t* __restrict__ hint,
+                                       const int32_t* __restrict__ stop) {
     __shared__ int32_t kd_stack[kSpThreads / 64][64];
+    if (stop && *stop) return;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t span = (n + 63) / 64 * 64; // whole waves walk the tree together
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < span; i += stride) {
@@ -252,7 +254,7 @@ int launch_spacing_session(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int64_t fi
                            int kind, double p0, double p1, double p2, T* d_spacing_pp, int32_t* d_hint) {
     SpacingLaw<T> law{kind, (T)p0, (T)p1, (T)p2};
     hipLaunchKernelGGL(spacing_session_kernel<T>, dim3(sp_grid(n)), dim3(kSpThreads), 0, ctx->stream, pts, n,
-                       (int32_t)first_id, (const KdNode<T>*)d_nodes, (int32_t)m, law, d_spacing_pp, d_hint);
+                       (int32_t)first_id, (const KdNode<T>*)d_nodes, (int32_t)m, law, d_spacing_pp, d_hint, ctx->stop_dev);
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;
 }

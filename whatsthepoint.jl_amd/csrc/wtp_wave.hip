@@ -59,6 +59,7 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const int32_t* __restrict__ list,
                                                         const int32_t* __restrict__ list_count, int all,
                                                         int part_base) {
+    if (a.stop && *a.stop) return; // wtp_relax_run_until: a stop rule fired earlier in this batch
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     using U = typename Bits<T>::U;
     const int wave = threadIdx.x >> 6;

@@ -337,6 +337,18 @@ class RelaxSession:
         """n_iters sweeps with no read-back at all (bench inner loop)."""
         L.check(self.ctx._h, self._lib.wtp_relax_run(self.ctx._h, int(n_iters), int(rebuild_every), None, None))
 
+    def run_until(self, max_iters: int, rebuild_every: int = 1, tol: float = 1e-6, stall_after: int = 50,
+                  cv_target: float = 0.0):
+        """The loop with the reference's stop rules evaluated on the device (src/repel.jl:305-334): returns
+        (conv, reason, last stats); reason 0 max_iters, 1 tol, 2 cv_target (positions reverted), 3 stall."""
+        conv = np.zeros(max(max_iters, 1), dtype=np.float64)
+        st = L.StepStats()
+        n_done, reason = C.c_int(0), C.c_int(0)
+        L.check(self.ctx._h, self._lib.wtp_relax_run_until(self.ctx._h, int(max_iters), int(rebuild_every), float(tol),
+                                                           int(stall_after), float(cv_target), _vp(conv), C.byref(n_done),
+                                                           C.byref(reason), C.byref(st)))
+        return conv[: n_done.value], int(reason.value), _stats_dict(st)
+
     def positions(self):
         out = np.empty((self.n - self.n_fixed, self.dim), dtype=self.dtype)
         L.check(self.ctx._h, self._lib.wtp_relax_get(self.ctx._h, _vp(out)))

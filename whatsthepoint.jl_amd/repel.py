@@ -75,7 +75,22 @@ def relax(p, snap_fixed, spacing, force_model, *, alpha_lo, alpha_max, k=21, max
             wall["octree"]._resident(ctx)
             sess.set_wall(wall["n_boundary"], wall["offset"])
         i = 1
-        while i <= max_iters:
+        if wall is None and trace is None and kick_after <= 0 and not variable and hasattr(sess, "run_until"):
+            # nothing needs the host between two sweeps: the whole loop, stop rules included (src/repel.jl:305-334),
+            # runs in the library — one call, no synchronisation per iteration
+            c, reason, _ = sess.run_until(max_iters, rebuild_every, tol, stall_after, cv_target)
+            conv.extend(float(v) for v in c)
+            n_it = len(conv)
+            if reason == 2:
+                log.info("Node repel stopped in %d iterations: spacing CV target reached", n_it)
+            elif reason == 3:
+                log.info("Node repel stopped in %d iterations: spacing CV stalled for %d iterations", n_it, stall_after)
+            elif reason == 1:
+                log.info("Node repel finished in %d iterations", n_it)
+            else:
+                log.warning("Node repel reached maximum iterations (%d), convergence=%g", max_iters, conv[-1])
+            i = -1  # (skips the host loop and its own max_iters warning)
+        while 0 < i <= max_iters:
             rebuild = (i - 1) % rebuild_every == 0
             if variable and i > 1:
                 # s = spacing(x_i) at the current position in EVERY sweep (src/repel.jl:260), not only on rebuilds
