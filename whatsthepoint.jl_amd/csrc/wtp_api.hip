@@ -265,6 +265,7 @@ static int knn_dev_t(wtp_ctx* ctx, const T* d_xyz, int64_t n, int dim, int k, in
     if ((rc = ensure(ctx, ctx->pts[1], sizeof(Pt<T>) * (size_t)n))) return rc;
     if ((rc = ensure(ctx, ctx->fb_list, sizeof(int32_t) * (size_t)n))) return rc;
     if ((rc = ensure(ctx, ctx->fb_count, 64))) return rc;
+    ctx->counters_clean = false; // (this call counts in the block; the next sweep clears it itself)
     if ((rc = ensure(ctx, ctx->fb2_list, sizeof(int32_t) * (size_t)n))) return rc;
     if ((rc = ensure(ctx, ctx->fb2_count, 64))) return rc;
     Pt<T>* raw = (Pt<T>*)ctx->pts[0].p;
@@ -337,6 +338,7 @@ static int knn_dev_f64(wtp_ctx* ctx, const double* d_xyz, int64_t n, int dim, in
     if ((rc = ensure(ctx, ctx->cand_dist, sizeof(float) * (size_t)n * kc))) return rc;
     if ((rc = ensure(ctx, ctx->fb_list, sizeof(int32_t) * (size_t)n))) return rc;
     if ((rc = ensure(ctx, ctx->fb_count, 64))) return rc;
+    ctx->counters_clean = false; // (this call counts in the block; the next sweep clears it itself)
     if ((rc = ensure(ctx, ctx->fb2_list, sizeof(int32_t) * (size_t)n))) return rc;
     if ((rc = ensure(ctx, ctx->fb2_count, 64))) return rc;
     if ((rc = ensure(ctx, ctx->occ, 64))) return rc;
@@ -647,6 +649,7 @@ template <typename T> static int radius_count_t(wtp_ctx* ctx, int64_t n, int dim
     a.n = (int32_t)n;
     if ((rc = ensure(ctx, ctx->fb_list, sizeof(int32_t) * (size_t)n))) return rc;
     if ((rc = ensure(ctx, ctx->fb_count, 64))) return rc;
+    ctx->counters_clean = false; // (this call counts in the block; the next sweep clears it itself)
     a.fb_list = (int32_t*)ctx->fb_list.p; // queries the brick kernel hands back to the wave kernel
     a.fb_count = (int32_t*)ctx->fb_count.p;
     sp = span_begin(ctx, 1);
@@ -861,6 +864,7 @@ static int relax_init_impl(wtp_ctx* ctx, const void* snap_xyz, bool on_device, i
     if ((rc = ensure(ctx, ctx->nn_id, sizeof(int32_t) * (size_t)n))) return rc;
     if ((rc = ensure(ctx, ctx->fb_list, sizeof(int32_t) * (size_t)n))) return rc;
     if ((rc = ensure(ctx, ctx->fb_count, 64))) return rc;
+    ctx->counters_clean = false; // (this call counts in the block; the next sweep clears it itself)
     if ((rc = ensure(ctx, ctx->fb2_list, sizeof(int32_t) * (size_t)n))) return rc;
     if ((rc = ensure(ctx, ctx->fb2_count, 64))) return rc;
     const int n_partials = total_partials();
@@ -1156,7 +1160,8 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
         a.cover_hi3[ax] = (T)r.cover_hi3[ax];
     }
     a.uncovered = (int32_t*)ctx->fb_count.p + 8;
-    WTP_HIP(ctx, hipMemsetAsync(ctx->fb_count.p, 0, 64, ctx->stream));
+    if (!ctx->counters_clean) WTP_HIP(ctx, hipMemsetAsync(ctx->fb_count.p, 0, 64, ctx->stream));
+    ctx->counters_clean = false; // (set again by the step's final reduction, which zeroes the block after reading it)
     a.used_brick = a.used_wave = a.used_generic = 0;
     if ((rc = launch_sweep<T>(ctx, a, fresh))) return rc;
     int sp = span_begin(ctx, 2);

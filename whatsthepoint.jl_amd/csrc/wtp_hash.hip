@@ -171,7 +171,9 @@ __global__ void grid_setup_kernel(const T* __restrict__ part, int nparts, Grid<T
 template <typename T>
 __global__ void cell_rank_kernel(const Pt<T>* __restrict__ pts, int64_t n, const Grid<T>* __restrict__ gp,
                                  int32_t* __restrict__ cell_cnt, int32_t* __restrict__ cell_rank,
-                                 uint8_t* __restrict__ dirty, int64_t v_old, int32_t v_fixed_old) {
+                                 uint8_t* __restrict__ dirty, int64_t v_old, int32_t v_fixed_old,
+                                 const int32_t* __restrict__ stop) {
+    if (stop && *stop) return; // (the counts and the dirty map must stay all-zero for the next real build)
     const Grid<T> g = *gp;
     const int lane = threadIdx.x & 63;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -280,7 +282,7 @@ __global__ void scan_top_kernel(int32_t* __restrict__ block_sums, const Grid<T>*
 }
 
 template <typename T>
-__global__ void scan_apply_kernel(const int32_t* __restrict__ cnt, const int32_t* __restrict__ block_sums,
+__global__ void scan_apply_kernel(int32_t* __restrict__ cnt, const int32_t* __restrict__ block_sums,
                                   const Grid<T>* __restrict__ gp, int32_t* __restrict__ cell_start,
                                   const int32_t* __restrict__ stop) {
     __shared__ int sm[kThreads / 64 + 1];
@@ -293,10 +295,11 @@ __global__ void scan_apply_kernel(const int32_t* __restrict__ cnt, const int32_t
     int s = 0;
     const bool whole = base + kScanTile <= ncells; // every tile but the last: 16-byte accesses, no bound checks
     if (whole) {
-        const int4* src = reinterpret_cast<const int4*>(cnt + base + threadIdx.x * kScanItems);
+        int4* src = reinterpret_cast<int4*>(cnt + base + threadIdx.x * kScanItems);
 #pragma unroll
         for (int q = 0; q < kScanItems / 4; ++q) {
             const int4 w = src[q];
+            src[q] = make_int4(0, 0, 0, 0); // the counts are consumed: left all-zero for the next build (no memset of 4 B x cells)
             v[4 * q] = w.x;
             v[4 * q + 1] = w.y;
             v[4 * q + 2] = w.z;
@@ -308,6 +311,7 @@ __global__ void scan_apply_kernel(const int32_t* __restrict__ cnt, const int32_t
         for (int j = 0; j < kScanItems; ++j) {
             int idx = base + threadIdx.x * kScanItems + j;
             v[j] = idx < ncells ? cnt[idx] : 0;
+            if (idx < ncells) cnt[idx] = 0;
             s += v[j];
         }
     }
@@ -374,12 +378,13 @@ static constexpr int kCanonMax = 96;
 template <typename T>
 __global__ __launch_bounds__(kThreads) void canon_kernel(Pt<T>* __restrict__ pts,
                                                          const int32_t* __restrict__ cell_start,
-                                                         const uint8_t* __restrict__ dirty,
+                                                         uint8_t* __restrict__ dirty,
                                                          const Grid<T>* __restrict__ gp, const int32_t* __restrict__ stop) {
     if (stop && *stop) return;
     const int ncells = gp->ncells;
     for (int cell = blockIdx.x * kThreads + threadIdx.x; cell < ncells; cell += gridDim.x * kThreads) {
         if (!dirty[cell]) continue; // filled by one run of the input: in order already
+        dirty[cell] = 0;            // consumed: the map is all-zero again for the next build
         const int s = cell_start[cell];
         const int m = cell_start[cell + 1] - s;
         if (m < 2 || m > kCanonMax) continue;
@@ -429,12 +434,12 @@ static int cell_capacity(const wtp_ctx* ctx, int64_t n, int k, double cell_scale
 
 // Occupancy as the points see it: sum cnt^2 / sum cnt = the mean, over points, of the number of
 // points sharing their cell (rho + 1 for a Poisson cloud of mean rho).
-__global__ void occupancy_kernel(const int32_t* __restrict__ cnt, const int32_t* __restrict__ ncells_p,
+__global__ void occupancy_kernel(const int32_t* __restrict__ cell_start, const int32_t* __restrict__ ncells_p,
                                  unsigned long long* __restrict__ out /* [sum cnt^2, sum cnt, max] */) {
     const int ncells = *ncells_p;
     unsigned long long s2 = 0, s1 = 0, mx = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ncells; i += gridDim.x * blockDim.x) {
-        const unsigned long long c = (unsigned long long)cnt[i];
+        const unsigned long long c = (unsigned long long)(cell_start[i + 1] - cell_start[i]); // (the counts themselves are consumed by the scan)
         s2 += c * c;
         s1 += c;
         mx = c > mx ? c : mx;
@@ -640,7 +645,7 @@ int launch_axis_hist(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int dim, const d
 
 int launch_occupancy(wtp_ctx* ctx, unsigned long long* d_out3) {
     WTP_HIP(ctx, hipMemsetAsync(d_out3, 0, 3 * sizeof(unsigned long long), ctx->stream));
-    hipLaunchKernelGGL(occupancy_kernel, dim3(1024), dim3(kThreads), 0, ctx->stream, (const int32_t*)ctx->cell_cnt.p,
+    hipLaunchKernelGGL(occupancy_kernel, dim3(1024), dim3(kThreads), 0, ctx->stream, (const int32_t*)ctx->cell_start.p,
                        (const int32_t*)ctx->ncells_dev, d_out3);
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;
@@ -663,6 +668,8 @@ int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, in
     const int32_t v_fixed_old = hv.active ? hv.fixed_old : 0, v_shift = hv.active ? hv.id_shift : 0;
     const int nbb = grid_for(n_in, kThreads, 1024);
     if ((rc = ensure(ctx, ctx->bbox_part, sizeof(double) * 6 * 1024))) return rc;
+    const void* cnt_before = ctx->cell_cnt.p;
+    const void* dirty_before = ctx->rank_of.p;
     if ((rc = ensure(ctx, ctx->cell_cnt, sizeof(int32_t) * (size_t)(cap + 1)))) return rc;
     if ((rc = ensure(ctx, ctx->cell_start, sizeof(int32_t) * (size_t)(cap + 2)))) return rc;
     if ((rc = ensure(ctx, ctx->cell_of, sizeof(int32_t) * (size_t)n_in))) return rc;
@@ -684,8 +691,14 @@ int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, in
     if (rho_direct > 0) rho_k = rho_direct; // caller fixes the occupancy (compact-support sweep)
     if (rho_k < 1.0) rho_k = 1.0;
 
-    WTP_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)(cap + 1), st));
-    WTP_HIP(ctx, hipMemsetAsync(dirty, 0, (size_t)cap + 64, st));
+    // Counts and dirty map are consumed (zeroed) by the scan and by the canonical-order pass of every build, so
+    // a build normally finds them all-zero: the two fills (4 + 1 bytes per cell) run only after a reallocation or
+    // after a build that did not complete.
+    if (!ctx->hash_scratch_clean || cnt_before != ctx->cell_cnt.p || dirty_before != ctx->rank_of.p) {
+        WTP_HIP(ctx, hipMemsetAsync(cnt, 0, ctx->cell_cnt.cap, st));
+        WTP_HIP(ctx, hipMemsetAsync(dirty, 0, ctx->rank_of.cap, st));
+    }
+    ctx->hash_scratch_clean = false;
     // ctx->reuse_grid (one-shot, set by the relax session): keep the Grid of the previous build — origin, cell edge,
     // cell counts — and skip the bounding-box pass.  A point that has left the old box since is clamped into an
     // edge cell, which the kernels treat as unbounded outward, so the search stays exact.
@@ -698,7 +711,8 @@ int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, in
     }
     ctx->ncells_dev = &g->ncells;
     const int nb = grid_for(n_in, kThreads, 16384);
-    hipLaunchKernelGGL(cell_rank_kernel<T>, dim3(nb), dim3(kThreads), 0, st, in, n_in, g, cnt, cr, dirty, v_old, v_fixed_old);
+    hipLaunchKernelGGL(cell_rank_kernel<T>, dim3(nb), dim3(kThreads), 0, st, in, n_in, g, cnt, cr, dirty, v_old, v_fixed_old,
+                       ctx->stop_dev);
     hipLaunchKernelGGL(scan_reduce_kernel<T>, dim3(nscan), dim3(kThreads), 0, st, cnt, g, bs);
     hipLaunchKernelGGL(scan_top_kernel<T>, dim3(1), dim3(kThreads), 0, st, bs, g);
     hipLaunchKernelGGL(scan_apply_kernel<T>, dim3(nscan), dim3(kThreads), 0, st, cnt, bs, g, start, ctx->stop_dev);
@@ -707,6 +721,7 @@ int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, in
     hipLaunchKernelGGL(canon_kernel<T>, dim3(grid_for(cap, kThreads, 8192)), dim3(kThreads), 0, st, out, start, dirty, g,
                        ctx->stop_dev);
     WTP_HIP(ctx, hipGetLastError());
+    ctx->hash_scratch_clean = true;
     return WTP_OK;
 }
 
@@ -917,7 +932,7 @@ int launch_gen_uniform(wtp_ctx* ctx, uint64_t seed, int64_t first, int64_t n, in
 __global__ void reduce_partials_kernel(const Partial* __restrict__ parts, int n_parts, int used_brick, int wave_base,
                                        int used_wave, int used_generic, const int32_t* __restrict__ fb_count,
                                        const int32_t* __restrict__ uncovered, const int32_t* __restrict__ escaped,
-                                       wtp_step_stats* __restrict__ out) {
+                                       wtp_step_stats* __restrict__ out, int32_t* __restrict__ counters) {
     __shared__ Acc sm[kThreads / 64];
     Acc acc = acc_empty();
     // only the slots this step's launches wrote (fixed order => deterministic): three ranges
@@ -950,13 +965,18 @@ __global__ void reduce_partials_kernel(const Partial* __restrict__ parts, int n_
         out->n_uncovered = uncovered ? *uncovered : 0;
         out->n_escaped = escaped ? *escaped : 0;
     }
+    // the step's counter block (hand-backs, uncovered, escaped, ...) has been read: all-zero for the next step
+    __syncthreads();
+    if (counters && threadIdx.x < 16) counters[threadIdx.x] = 0;
 }
 
 int launch_reduce_partials(wtp_ctx* ctx, const Partial* parts, int n_parts, int used_brick, int used_wave,
                            int used_generic, const int32_t* fb_count, const int32_t* uncovered, const int32_t* escaped,
                            wtp_step_stats* d_slot) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kThreads), 0, ctx->stream, parts, n_parts, used_brick,
-                       brick_partials(), used_wave, used_generic, fb_count, uncovered, escaped, d_slot);
+                       brick_partials(), used_wave, used_generic, fb_count, uncovered, escaped, d_slot,
+                       (int32_t*)ctx->fb_count.p);
+    ctx->counters_clean = true;
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;
 }

@@ -228,6 +228,8 @@ struct wtp_ctx {
     wtp::DevBuf cand_idx, cand_dist, f32_pts; // fp64 topology: fp32 candidate lists and the float copy of the cloud
     wtp::DevBuf forces, nn_dist, nn_id, spacing_pp;
     wtp::DevBuf partials, stats, fb_list, fb_count, fb2_list, fb2_count, nn_list;
+    bool hash_scratch_clean = false;  // cell counts and dirty map are all-zero (every completed build leaves them so)
+    bool counters_clean = false;      // the 64-byte counter block is all-zero (the step's final reduction leaves it so)
     wtp::DevBuf stop_state;           // wtp_relax_run_until: {stopped, reason, n_done, last_impr, best_cv} on the device
     const int32_t* stop_dev = nullptr; // its first word while such a run is enqueued, else NULL (kernels then never look)
     wtp::DevBuf scratch;       // misc (relax_get staging, radius rows)
