@@ -985,10 +985,25 @@ static int cs2_tune(wtp_ctx* ctx, RelaxState& r, const Grid<float>& hg, double r
         bx = nbx;
     }
     // equal bricks along x: n[0] = 214 cells cut into bricks of 51 leaves a fifth brick of 10 cells that pays the
-    // whole per-brick setup for a fifth of the work; cut into ceil(n/bx) equal parts instead (never longer)
-    if (hg.n[0] > bx) {
-        const int parts = (hg.n[0] + bx - 1) / bx;
-        bx = (hg.n[0] + parts - 1) / parts;
+    // whole per-brick setup for a fifth of the work.  Cut the row into equal parts instead — as few as the two
+    // limits (one round of the workgroup for 97 % of the bricks, the LDS point area) allow.
+    if (hg.n[0] > bx && q97 > 0) {
+        int best = 0;
+        for (int parts = hg.n[0] / bx > 1 ? hg.n[0] / bx : 1; parts <= (hg.n[0] + bx - 1) / bx; ++parts) {
+            const int bxc = (hg.n[0] + parts - 1) / parts;
+            if (bxc > bx_max) continue;
+            const double grow = (double)bxc / (double)bx;
+            if (q97 * grow <= 254.0 && h999 * grow <= 1100.0) {
+                best = bxc;
+                h999 = (int)(h999 * grow) + 1;
+                break; // the fewest parts that fit
+            }
+        }
+        if (!best) {
+            const int parts = (hg.n[0] + bx - 1) / bx;
+            best = (hg.n[0] + parts - 1) / parts;
+        }
+        bx = best;
     }
     int hc = (int)(h999 * 1.05) + 48;
     hc = (hc + 63) / 64 * 64;
