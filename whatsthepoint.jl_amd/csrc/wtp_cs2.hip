@@ -436,8 +436,9 @@ __global__ __launch_bounds__(kCsThreads, 4) void cs2_kernel(SearchArgs<float> a,
             bool giveup = (ea - pa0) > 255u * 16u;
             float tau_s = (cs_fail || giveup) ? -1.f : lim * (1.f + 0x1p-21f); // FMA filter, 4 ulp wide; the ring pass is exact
             const uint32_t ring_b = ring_off + (uint32_t)tid * (uint32_t)kCsRingStride;
-            uint32_t ra = ring_b; // next free ring byte (the running address itself: one add-with-carry per candidate)
             const uint32_t lds_base = (uint32_t)(uintptr_t)smem_raw;
+            const uint32_t ring_a = lds_base + ring_b; // LDS address of this lane's ring
+            uint32_t ra = ring_a; // next free ring byte (the running address itself: one add-with-carry per candidate)
             CS_STAMP(1) // query setup
             if (WTP_DIAG) {
                 dt[9] += 1;                                           // query rounds (per wave)
@@ -449,10 +450,10 @@ __global__ __launch_bounds__(kCsThreads, 4) void cs2_kernel(SearchArgs<float> a,
                     dt[11] += 1; // scan steps (per wave)
                     dt[12] += (unsigned long long)__popcll(__ballot(pa < ea)); // busy lanes
                 }
-                if (__any(ra > ring_b + (uint32_t)kCsRing)) { // a lane's ring is full (dense cluster): that lane gives up
-                    if (ra > ring_b + (uint32_t)kCsRing) {
+                if (__any(ra > ring_a + (uint32_t)kCsRing)) { // a lane's ring is full (dense cluster): that lane gives up
+                    if (ra > ring_a + (uint32_t)kCsRing) {
                         giveup = true;
-                        ra = ring_b;
+                        ra = ring_a;
                         tau_s = -1.f;
                     }
                 }
@@ -463,24 +464,33 @@ __global__ __launch_bounds__(kCsThreads, 4) void cs2_kernel(SearchArgs<float> a,
                 const float thr = busy ? tau_s : -1.f;
                 const uint32_t addr = lds_base + (busy ? pa : pa0);
                 cs_f4 c[4]; // two half steps: 16 registers of candidates instead of 32 (the next brick's loads sit in registers too)
+                // append = compare, unconditional byte store at the running ring address, add-with-carry of the
+                // compare's bit to that address: three instructions per candidate besides the six of the distance
+                // (written out: the compiler turns `ra += take` into select + add, one instruction more per candidate)
+#define CS_APPEND(dist, val)                                                                            \
+    asm volatile("v_cmp_le_f32 vcc, %1, %2\n\tds_write_b8 %0, %3\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" \
+                 : "+v"(ra)                                                                              \
+                 : "v"(dist), "v"(thr), "v"(val)                                                         \
+                 : "vcc", "memory")
                 cs_read_group<0>(c, addr);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const float ex = qp.x - c[u].x, ey = qp.y - c[u].y, ez = qp.z - c[u].z;
                     const float d = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
-                    smem_raw[ra] = (unsigned char)(idx0 + u); // unconditional: rewritten or never read
-                    ra += (d <= thr) ? 1u : 0u;
+                    const uint32_t val = idx0 + (uint32_t)u; // slot index inside the run; rewritten or never read when not taken
+                    CS_APPEND(d, val);
                 }
                 cs_read_group<64>(c, addr);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const float ex = qp.x - c[u].x, ey = qp.y - c[u].y, ez = qp.z - c[u].z;
                     const float d = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
-                    smem_raw[ra] = (unsigned char)(idx0 + 4 + u);
-                    ra += (d <= thr) ? 1u : 0u;
+                    const uint32_t val = idx0 + 4u + (uint32_t)u;
+                    CS_APPEND(d, val);
                 }
+#undef CS_APPEND
             }
-            const uint32_t cnt = ra - ring_b;
+            const uint32_t cnt = ra - ring_a;
             CS_STAMP(2) // scan
 
             // ---- ring pass: canonical d2 of every survivor, exact cut, force sum (src/repel.jl:270-280) ----
