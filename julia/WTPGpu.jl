@@ -108,38 +108,91 @@ function relax_get(D, T, n_move)
     return out
 end
 
-# The loop of _relax! with the sweep on the device; stop rules exactly as src/repel.jl:305-334.
-# (`constrain`, kick and trace stay with the caller's code path: see INTEGRATION.md for the octree method.)
+function relax_set_spacing(s::Vector)                     # per-point spacings of the whole snapshot, the cloud's eltype
+    GC.@preserve s check(context(), ccall((:wtp_relax_set_spacing, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), context(), pointer(s)))
+end
+# the whole loop with the stop rules evaluated on the device (include/wtp.h: wtp_relax_run_until)
+function relax_run_until(max_iters::Int, rebuild_every::Int, tol, stall_after::Int, cv_target)
+    conv = zeros(Float64, max(max_iters, 1)); n_done = Ref{Cint}(0); reason = Ref{Cint}(0); st = StepStats()
+    check(context(), ccall((:wtp_relax_run_until, lib), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Float64, Cint, Float64, Ptr{Float64}, Ref{Cint}, Ref{Cint}, Ref{StepStats}),
+        context(), max_iters, rebuild_every, Float64(tol), stall_after, Float64(cv_target), conv, n_done, reason, st))
+    return conv[1:n_done[]], Int(reason[])               # reason: 0 max_iters, 1 tol, 2 cv_target (reverted), 3 stall
+end
+
+# The loop of _relax! (src/repel.jl:243-339) with rebuild + sweep + reductions on the device.
+#  * constant spacing, no kick, no trace: ONE ccall — the stop rules (src/repel.jl:305-334) run on the device;
+#  * otherwise one ccall per iteration, the rules below exactly as the reference applies them, the spacing
+#    callable re-evaluated before every sweep (s = spacing(xi), src/repel.jl:260; the array the CV monitor and the
+#    kick read is the one of src/repel.jl:251), kick and trace as in src/repel.jl:294-304,396-433.
+# (`constrain` of the octree method: wtp_relax_set_wall, see INTEGRATION.md.)
 function relax!(p, p_old, snap, spacing, force_model; n_fixed, α_lo, α_max, k, max_iters, tol, rebuild_every,
-                stall_after = 0, cv_target = 0.0)
+                stall_after = 0, cv_target = 0.0, kick_after = 0, trace = nothing, n_protected = n_fixed)
     rebuild_every >= 1 || throw(ArgumentError("rebuild_every must be ≥ 1"))
-    s = ustrip.(spacing.(snap))
-    D, T, n_move = relax_init(snap, n_fixed, all(==(first(s)), s) ? first(s) : s, force_model, min(k, length(snap)),
+    T = eltype(WhatsThePoint._raw_point(first(snap)))
+    s = T.(ustrip.(spacing.(snap)))                        # the ABI reads n values of the CLOUD's float type
+    constant = all(==(first(s)), s)
+    D, _, n_move = relax_init(snap, n_fixed, constant ? first(s) : s, force_model, min(k, length(snap)),
                               ustrip(α_lo), ustrip(α_max))
-    conv = T[]; best_cv = Inf; last_improvement = 0; i = 1
+    conv = T[]
+    u = unit(Meshes.to(first(p))[1])
     try
-        while i <= max_iters
-            st = relax_step((i - 1) % rebuild_every == 0)
-            push!(conv, T(st.max_force))
-            if (stall_after > 0 || cv_target > 0) && st.n_move > 0
-                μ = st.sum_u / st.n_move
-                cv = sqrt(max(st.sum_u2 / st.n_move - μ^2, 0)) / μ
-                if cv_target > 0 && cv <= cv_target
-                    relax_revert(); break
+        if constant && kick_after <= 0 && trace === nothing
+            c, _ = relax_run_until(max_iters, rebuild_every, tol, stall_after, cv_target)
+            append!(conv, T.(c))
+        else
+            best_cv = Inf; last_improvement = 0; i = 1
+            kick_pair = (0, 0); kick_rs = Inf; kick_count = 0
+            while i <= max_iters
+                if !constant && i > 1                      # s = spacing(xi) at the current positions, every sweep
+                    cur = relax_get(D, T, n_move)
+                    for j in 1:n_move
+                        s[n_fixed + j] = T(ustrip(spacing(Meshes.Point((cur[j] .* u)...))))
+                    end
+                    relax_set_spacing(s)
                 end
-                if stall_after > 0
-                    if cv < best_cv * (1 - 1.0e-3)
-                        best_cv, last_improvement = cv, i
-                    elseif i - last_improvement >= stall_after
-                        break
+                st = relax_step((i - 1) % rebuild_every == 0)
+                push!(conv, T(st.max_force))
+                if n_move > 0 && (trace !== nothing || kick_after > 0)   # _closest_pair, src/repel.jl:396-403
+                    a, b = st.argmin_i + 1, st.argmin_j + 1             # 1-based snapshot indices
+                    sp = b > 0 ? (s[a] + s[b]) / 2 : s[a]
+                    pair = (r = st.argmin_r, s = sp, r_over_s = st.argmin_r / sp, idx_a = min(a, b), idx_b = max(a, b))
+                    trace !== nothing && push!(trace, (iteration = i, pair...))
+                    if kick_after > 0                                    # _maybe_kick!, src/repel.jl:415-433
+                        frozen = (pair.idx_a, pair.idx_b) == kick_pair && abs(pair.r_over_s - kick_rs) < 1.0e-8
+                        kick_count = frozen ? kick_count + 1 : 1
+                        kick_pair = (pair.idx_a, pair.idx_b); kick_rs = pair.r_over_s
+                        if kick_count >= kick_after
+                            t = pair.idx_a > n_protected ? pair.idx_a : (pair.idx_b > n_protected ? pair.idx_b :
+                                (pair.idx_a > n_fixed ? pair.idx_a : pair.idx_b))
+                            if t > n_fixed
+                                cur = relax_get(D, T, n_move)
+                                d = randn(T, D); d ./= sqrt(sum(abs2, d))
+                                relax_set(t - n_fixed, cur[t - n_fixed] .+ T(0.1) * s[t] .* d)
+                            end
+                            kick_count = 0
+                        end
                     end
                 end
+                if (stall_after > 0 || cv_target > 0) && st.n_move > 0
+                    μ = st.sum_u / st.n_move
+                    cv = sqrt(max(st.sum_u2 / st.n_move - μ^2, 0)) / μ
+                    if cv_target > 0 && cv <= cv_target
+                        relax_revert(); break
+                    end
+                    if stall_after > 0
+                        if cv < best_cv * (1 - 1.0e-3)
+                            best_cv, last_improvement = cv, i
+                        elseif i - last_improvement >= stall_after
+                            break
+                        end
+                    end
+                end
+                conv[end] < tol && break
+                i += 1
             end
-            conv[end] < tol && break
-            i += 1
         end
         raws = relax_get(D, T, n_move)
-        u = unit(Meshes.to(first(p))[1])
         for j in eachindex(p)
             p[j] = Meshes.Point((raws[j] .* u)...)
         end
@@ -147,6 +200,19 @@ function relax!(p, p_old, snap, spacing, force_model; n_fixed, α_lo, α_max, k,
         relax_end()
     end
     return conv
+end
+
+# ---- set_topology / rebuild_topology! (src/cloud.jl:200-228, src/surface.jl:167-205, src/volume.jl:97-125) ----------
+# The containers stay the reference's; only the adjacency comes from the device.
+knn_topology(pts, k::Int) = WhatsThePoint.KNNTopology(build_knn_neighbors(pts, k), k)
+radius_topology(pts, radius) = WhatsThePoint.RadiusTopology(build_radius_neighbors(pts, radius), radius)
+function rebuild_topology!(topo::WhatsThePoint.KNNTopology, pts)
+    topo.neighbors = build_knn_neighbors(pts, topo.k)     # in place, like src/topology.jl:116-121
+    return nothing
+end
+function rebuild_topology!(topo::WhatsThePoint.RadiusTopology, pts)
+    topo.neighbors = build_radius_neighbors(pts, topo.radius)
+    return nothing
 end
 
 end # module
