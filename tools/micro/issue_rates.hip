@@ -13,7 +13,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // KIND 0 v_fma_f32  1 v_pk_fma_f32  2 v_add_u32  3 v_min_u32  4 v_cmp_le_f32+v_cndmask (2 instr)
 //      5 v_mfma_f32_16x16x4_f32 alone  6 MFMA + 4 VALU  7 MFMA + 8 VALU  8 MFMA + 12 VALU
-//      9 v_mul_f32  10 v_sub_f32  11 v_and_b32
+//      9 v_mul_f32  10 v_sub_f32  11 v_and_b32  12 v_min_f32  13 v_max_u32  14 v_min_i32  15 v_med3_f32  16 v_min3_u32
 constexpr int kUnroll = 16;
 
 template <int KIND>
@@ -61,6 +61,21 @@ __global__ __launch_bounds__(256, 8) void k(uint64_t* cyc, float* sink, int iter
         } else if (KIND == 11) {
 #pragma unroll
             for (int i = 0; i < kUnroll; ++i) asm volatile("v_and_b32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) % kUnroll]));
+        } else if (KIND == 12) {
+#pragma unroll
+            for (int i = 0; i < kUnroll; ++i) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i]) : "v"(a[(i + 1) % kUnroll]));
+        } else if (KIND == 13) {
+#pragma unroll
+            for (int i = 0; i < kUnroll; ++i) asm volatile("v_max_u32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) % kUnroll]));
+        } else if (KIND == 14) {
+#pragma unroll
+            for (int i = 0; i < kUnroll; ++i) asm volatile("v_min_i32 %0, %0, %1" : "+v"(u[i]) : "v"(u[(i + 1) % kUnroll]));
+        } else if (KIND == 15) {
+#pragma unroll
+            for (int i = 0; i < kUnroll; ++i) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(a[(i + 1) % kUnroll]), "v"(m));
+        } else if (KIND == 16) {
+#pragma unroll
+            for (int i = 0; i < kUnroll; ++i) asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(u[i]) : "v"(u[(i + 1) % kUnroll]), "v"(u[(i + 2) % kUnroll]));
         } else {
             constexpr int NV = KIND == 5 ? 0 : (KIND == 6 ? 4 : (KIND == 7 ? 8 : 12));
 #pragma unroll
@@ -74,11 +89,11 @@ __global__ __launch_bounds__(256, 8) void k(uint64_t* cyc, float* sink, int iter
     const uint64_t t1 = __builtin_amdgcn_s_memtime();
     const uint64_t r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0.f;
-    if (KIND == 0 || KIND == 4 || KIND == 9 || KIND == 10 || KIND >= 5) {
+    if (KIND == 0 || KIND == 4 || KIND == 9 || KIND == 10 || KIND == 12 || KIND == 15 || (KIND >= 5 && KIND <= 8)) {
 #pragma unroll
         for (int i = 0; i < kUnroll; ++i) s += a[i];
     }
-    if (KIND == 2 || KIND == 3 || KIND == 11) {
+    if (KIND == 2 || KIND == 3 || KIND == 11 || KIND == 13 || KIND == 14 || KIND == 16) {
 #pragma unroll
         for (int i = 0; i < kUnroll; ++i) s += (float)u[i];
     }
@@ -133,7 +148,8 @@ __global__ __launch_bounds__(256) void kmix(uint64_t* cyc, float* sink, int iter
 
 static const char* names[] = {"v_fma_f32", "v_pk_fma_f32", "v_add_u32", "v_min_u32", "v_cmp_le_f32+v_cndmask_b32",
                               "v_mfma_f32_16x16x4_f32", "mfma16x16x4 + 4 v_fma", "mfma16x16x4 + 8 v_fma",
-                              "mfma16x16x4 + 12 v_fma", "v_mul_f32", "v_sub_f32", "v_and_b32"};
+                              "mfma16x16x4 + 12 v_fma", "v_mul_f32", "v_sub_f32", "v_and_b32", "v_min_f32", "v_max_u32", "v_min_i32",
+                              "v_med3_f32", "v_min3_u32"};
 
 template <int KIND> static void run(uint64_t* dc, float* ds, int wps) {
     const int iters = 100000;
@@ -182,6 +198,11 @@ int main() {
         run<9>(dc, ds, wps);
         run<10>(dc, ds, wps);
         run<11>(dc, ds, wps);
+        run<12>(dc, ds, wps);
+        run<13>(dc, ds, wps);
+        run<14>(dc, ds, wps);
+        run<15>(dc, ds, wps);
+        run<16>(dc, ds, wps);
         run<5>(dc, ds, wps);
         run<6>(dc, ds, wps);
         run<7>(dc, ds, wps);

@@ -103,7 +103,11 @@ __device__ inline float cs_step_point(const SearchArgs<float>& a, float s, float
 
 __device__ inline void cs_acc_point(CsAcc& c, float force, float nd, float s, int32_t id, int32_t nn) {
     c.max_force = force > c.max_force ? force : c.max_force;
-    const double u = (double)(nd * __builtin_amdgcn_rcpf(s));
+    // d_nn / s in T as the reference's CV monitor divides (src/repel.jl:374-384): reciprocal + one exact-residual
+    // correction = the correctly rounded quotient (but for rare near-halfway cases, 1 ulp, invisible in the sums);
+    // the IEEE sequence costs registers this kernel does not have
+    const float rs = __builtin_amdgcn_rcpf(s), q0 = nd * rs;
+    const double u = (double)__builtin_fmaf(__builtin_fmaf(-s, q0, nd), rs, q0);
     c.sum_u += u;
     c.sum_u2 += u * u;
     c.n_move += 1;

@@ -375,37 +375,76 @@ static constexpr int kCanonMax = 96;
 // marking candidate cells in cell_rank_kernel (bitmap / byte map) and visiting only those 91-97 us (a third
 // of the cells exchange a point per iteration, and the marks cost atomics or a second memset); a register
 // rank sort with all loads in flight 125 us.  The pass is bound by touching the lines the scatter just wrote.
+// Round 2: the dirty map is read 16 cells per lane (one 16-byte load; a lane that finds a mark clears its 16 bytes),
+// the marked cells of a wave are queued in LDS and handed out one per lane — the marks are few (a cell is marked
+// only when it collected several runs), so a thread per cell spent its time on byte loads and on lanes waiting
+// for the one lane of the wave that had work.  97 -> see DESIGN.md §4 (hash).
 template <typename T>
 __global__ __launch_bounds__(kThreads) void canon_kernel(Pt<T>* __restrict__ pts,
                                                          const int32_t* __restrict__ cell_start,
                                                          uint8_t* __restrict__ dirty,
                                                          const Grid<T>* __restrict__ gp, const int32_t* __restrict__ stop) {
+    __shared__ int32_t queue[kThreads / 64][64 * 16];
     if (stop && *stop) return;
     const int ncells = gp->ncells;
-    for (int cell = blockIdx.x * kThreads + threadIdx.x; cell < ncells; cell += gridDim.x * kThreads) {
-        if (!dirty[cell]) continue; // filled by one run of the input: in order already
-        dirty[cell] = 0;            // consumed: the map is all-zero again for the next build
-        const int s = cell_start[cell];
-        const int m = cell_start[cell + 1] - s;
-        if (m < 2 || m > kCanonMax) continue;
-        bool sorted = true;
-        int prev = w_to_id(pts[s].w);
-        for (int i = 1; i < m; ++i) {
-            const int cur = w_to_id(pts[s + i].w);
-            sorted = sorted && prev <= cur;
-            prev = cur;
+    const int ngroups = (ncells + 15) / 16; // (the map is allocated 64 bytes past the cell capacity and all-zero there)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t* q = queue[wave];
+    const int nwave_groups = (ngroups + 63) / 64;
+    for (int wg = blockIdx.x * (kThreads / 64) + wave; wg < nwave_groups; wg += gridDim.x * (kThreads / 64)) {
+        const int grp = wg * 64 + lane;
+        uint4 m = make_uint4(0u, 0u, 0u, 0u);
+        if (grp < ngroups) m = reinterpret_cast<const uint4*>(dirty)[grp];
+        const bool any = (m.x | m.y | m.z | m.w) != 0u;
+        if (!__any(any)) continue;
+        if (any) reinterpret_cast<uint4*>(dirty)[grp] = make_uint4(0u, 0u, 0u, 0u); // consumed: all-zero again for the next build
+        // marks are bytes of value 1: bit 8 j of word w <-> cell 16 grp + 4 w + j
+        const uint32_t w[4] = {m.x, m.y, m.z, m.w};
+        int mine = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mine += __popc(w[k] & 0x01010101u);
+        int incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
         }
-        if (sorted) continue;
-        for (int i = 1; i < m; ++i) {
-            const Pt<T> key = pts[s + i];
-            const int kid = w_to_id(key.w);
-            int j = i - 1;
-            while (j >= 0 && w_to_id(pts[s + j].w) > kid) {
-                pts[s + j + 1] = pts[s + j];
-                --j;
+        const int total = __shfl(incl, 63, 64);
+        int pos = incl - mine;
+        if (any) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if ((w[k] >> (8 * j)) & 1u) q[pos++] = grp * 16 + k * 4 + j;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int e = lane; e < total; e += 64) {
+            const int cell = q[e];
+            if (cell >= ncells) continue;
+            const int s = cell_start[cell];
+            const int n_in = cell_start[cell + 1] - s;
+            if (n_in < 2 || n_in > kCanonMax) continue;
+            bool sorted = true;
+            int prev = w_to_id(pts[s].w);
+            for (int i = 1; i < n_in; ++i) {
+                const int cur = w_to_id(pts[s + i].w);
+                sorted = sorted && prev <= cur;
+                prev = cur;
             }
-            pts[s + j + 1] = key;
+            if (sorted) continue;
+            for (int i = 1; i < n_in; ++i) {
+                const Pt<T> key = pts[s + i];
+                const int kid = w_to_id(key.w);
+                int j = i - 1;
+                while (j >= 0 && w_to_id(pts[s + j].w) > kid) {
+                    pts[s + j + 1] = pts[s + j];
+                    --j;
+                }
+                pts[s + j + 1] = key;
+            }
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -718,8 +757,8 @@ int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, in
     hipLaunchKernelGGL(scan_apply_kernel<T>, dim3(nscan), dim3(kThreads), 0, st, cnt, bs, g, start, ctx->stop_dev);
     hipLaunchKernelGGL(scatter_kernel<T>, dim3(nb), dim3(kThreads), 0, st, in, n_in, cr, g, start, out, v_old, v_fixed_old,
                        v_shift, ctx->stop_dev);
-    hipLaunchKernelGGL(canon_kernel<T>, dim3(grid_for(cap, kThreads, 8192)), dim3(kThreads), 0, st, out, start, dirty, g,
-                       ctx->stop_dev);
+    hipLaunchKernelGGL(canon_kernel<T>, dim3(grid_for((cap + 15) / 16, kThreads, 4096)), dim3(kThreads), 0, st, out, start, dirty,
+                       g, ctx->stop_dev);
     WTP_HIP(ctx, hipGetLastError());
     ctx->hash_scratch_clean = true;
     return WTP_OK;
