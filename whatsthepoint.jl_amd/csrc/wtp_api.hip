@@ -77,12 +77,20 @@ static int take_event(wtp_ctx* ctx) {
     return ctx->ev_used++;
 }
 
+// Spans of a step follow each other without a gap (hash | sweep | follow-ups | reduction | next hash ...), so the
+// event that closes one opens the next: one record per span instead of two (an event record costs ~4 us of stream
+// time; eight per step were a third of a 50 k-point step).  Work enqueued between two spans counts for the later one.
 int span_begin(wtp_ctx* ctx, int kind) {
     if (!ctx->timing) return -1;
     if (ctx->spans.size() > 8192) spans_collect(ctx); // bounded pool; costs one sync
-    int a = take_event(ctx), b = take_event(ctx);
-    if (a < 0 || b < 0) return -1;
-    hipEventRecord(ctx->ev_pool[a], ctx->stream);
+    int a = ctx->ev_last_end;
+    if (a < 0) {
+        a = take_event(ctx);
+        if (a < 0) return -1;
+        hipEventRecord(ctx->ev_pool[a], ctx->stream);
+    }
+    const int b = take_event(ctx);
+    if (b < 0) return -1;
     ctx->spans.push_back({a, b, kind});
     return (int)ctx->spans.size() - 1;
 }
@@ -90,9 +98,11 @@ int span_begin(wtp_ctx* ctx, int kind) {
 void span_end(wtp_ctx* ctx, int span) {
     if (span < 0) return;
     hipEventRecord(ctx->ev_pool[ctx->spans[span].b], ctx->stream);
+    ctx->ev_last_end = ctx->spans[span].b;
 }
 
 void spans_collect(wtp_ctx* ctx) {
+    ctx->ev_last_end = -1; // the pool is recycled below (and a caller that reads the timers has synchronised: a gap)
     if (ctx->spans.empty()) return;
     hipStreamSynchronize(ctx->stream);
     for (auto& s : ctx->spans) {
@@ -108,6 +118,7 @@ void spans_collect(wtp_ctx* ctx) {
 }
 
 static int sync(wtp_ctx* ctx) {
+    ctx->ev_last_end = -1; // the host waits here: whatever it does next is not part of a span
     WTP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return WTP_OK;
 }
@@ -304,6 +315,8 @@ static int knn_dev_t(wtp_ctx* ctx, const T* d_xyz, int64_t n, int dim, int k, in
     a.fb_count = (int32_t*)ctx->fb_count.p;
     a.fb2_list = (int32_t*)ctx->fb2_list.p;
     a.fb2_count = (int32_t*)ctx->fb2_count.p;
+    if ((rc = ensure(ctx, ctx->diag, 128))) return rc;
+    a.diag = (unsigned long long*)ctx->diag.p; // (written by -DWTP_DIAG builds only)
     sp = span_begin(ctx, 1);
     rc = launch_topology<T>(ctx, a);
     span_end(ctx, sp);
@@ -467,7 +480,10 @@ WTP_API int wtp_create(const int* device_ordinals, int n_dev, wtp_ctx** out) {
     if (const char* e = getenv("WTP_CS2")) ctx->cs2 = atoi(e);
     if (const char* e = getenv("WTP_RHO_CS")) ctx->rho_cs2 = atof(e) >= 1.0 ? atof(e) : ctx->rho_cs2;
     if (const char* e = getenv("WTP_STYP_SIGMA")) ctx->styp_sigma = atof(e);
-    if (const char* e = getenv("WTP_TIMING")) ctx->timing = atoi(e) != 0;
+    if (const char* e = getenv("WTP_TIMING")) {
+        ctx->timing = atoi(e) != 0;
+        ctx->timing_forced = true;
+    }
     if (const char* e = getenv("WTP_MESH_PACKET")) ctx->mesh_packet = atoi(e);
     if (const char* e = getenv("WTP_GRID_REUSE")) ctx->grid_reuse_max = atoi(e) >= 0 ? atoi(e) : ctx->grid_reuse_max;
     *out = ctx;
@@ -1958,6 +1974,7 @@ WTP_API int wtp_timers_reset(wtp_ctx* ctx) {
     spans_collect(ctx);
     ctx->t_hash = ctx->t_sweep = ctx->t_other = 0;
     ctx->n_sweep_launches = 0;
+    if (!ctx->timing_forced) ctx->timing = true; // the caller is going to read the timers
     return WTP_OK;
 }
 

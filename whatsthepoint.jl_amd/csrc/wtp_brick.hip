@@ -155,6 +155,34 @@ __device__ inline void ring_select(const float4* __restrict__ pts, const uint16_
     }
 }
 
+// KNNTopology rows (round 2): ONE network instead of two.  The key is the upper 26 bits of d2 with the ring position
+// in the low 6: truncation is monotone, so entries whose truncated d2 differ come out in exact order, and the low
+// bits lead back to the candidate — no second pass that compacts the survivors and sorts 64-bit (d2, id) keys.
+// Entries that share a truncated d2 (relative difference < 2^-17: ~0.5 % of the queries have such a pair among
+// their k nearest) are put in exact (d2, id) order afterwards by the caller; a shared bucket AT the cut sends the
+// query to the exact path, like an exact tie did before.
+constexpr uint32_t kSlotMask = 63u;
+static_assert(NB == 64, "ring position rides in 6 bits of the key");
+template <int KT>
+__device__ inline void ring_sort_packed(const float4* __restrict__ pts, const uint16_t* __restrict__ ring, int cnt,
+                                        float qx, float qy, float qz, uint32_t (&k)[NB]) {
+#pragma unroll
+    for (int c8 = 0; c8 < NB / 8; ++c8) {
+        if (__any(cnt > c8 * 8)) { // wave-uniform: skip chunks no lane has filled
+#pragma unroll
+            for (int j = c8 * 8; j < c8 * 8 + 8; ++j) {
+                const float4 c = lds_pt(pts, ring[(j < cnt ? j : 0) * kBrickThreads]);
+                const uint32_t d = f2u(dist2<float>(qx, qy, qz, c.x, c.y, c.z));
+                k[j] = j < cnt ? ((d & ~kSlotMask) | (uint32_t)j) : (0x7F800000u | (uint32_t)j);
+            }
+        } else {
+#pragma unroll
+            for (int j = c8 * 8; j < c8 * 8 + 8; ++j) k[j] = 0x7F800000u | (uint32_t)j;
+        }
+    }
+    WTP_SORTNET_64(k)
+}
+
 // Keep ring entries with d2 <= lim (stable, in place).
 __device__ inline void ring_compact(const float4* __restrict__ pts, uint16_t* __restrict__ ring, int& cnt,
                                     float lim, float qx, float qy, float qz) {
@@ -456,6 +484,8 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
                 ea = (uint32_t)sm->hstart[base + 3] * 16u;
             }
             uint32_t kth = 0, next = 0;
+            uint32_t keys[NB]; // MODE 0: the ring sorted by packed key (ring_sort_packed); unused otherwise
+            constexpr int kPre = (KT > 0 ? KT : kFastKMax - 1) + 3; // sorted prefix the topology path looks at (K <= kFastKMax - 1)
             int rbase_l = ((hz - 1) * HY + (hy - 1)) * HX + (hx - 1); // CS lane rows: hstart index of my row
             bool lr_started = false; // CS trimmed lane rows: first entry vs resume after ring pressure
             uint32_t lr_q[9] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}; // queued runs: start | end << 16 (byte offsets)
@@ -647,8 +677,23 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
                         spec.reset();
                         ring_select<KT>(pts, ring, cnt, qp.x, qp.y, qp.z, K, kth, next, spec);
                     } else {
-                        NoVisit nv;
-                        ring_select<KT>(pts, ring, cnt, qp.x, qp.y, qp.z, K, kth, next, nv);
+                        ring_sort_packed<KT>(pts, ring, cnt, qp.x, qp.y, qp.z, keys);
+                        // the cut as the upper end of the k-th entry's bucket: "d2 <= cut" is then exactly the
+                        // sorted prefix, and kth == next says that the (k+1)-th shares the bucket
+                        if (KT > 0) {
+                            kth = keys[KT - 1];
+                            next = keys[KT];
+                        } else {
+                            kth = keys[0];
+                            next = keys[1];
+#pragma unroll
+                            for (int j = 1; j < kFastKMax; ++j) {
+                                kth = (j == K - 1) ? keys[j] : kth;
+                                next = (j == K - 1) ? keys[j + 1] : next;
+                            }
+                        }
+                        kth |= kSlotMask;
+                        next |= kSlotMask;
                     }
                     DIAG_STAMP(3) // select
                 }
@@ -657,6 +702,26 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
                     const float t = u2f(kth);
                     tau = t < tau ? t : tau;
                 }
+                if (MODE == 0) {
+                    // survivors = the sorted prefix: the K nearest so far plus up to two more from the k-th's bucket
+                    // (a bucket that reaches further is a mass tie: exact path).  Their candidates are looked up
+                    // through the low key bits and rewritten to the head of the ring.
+                    const int keep = cnt < K + 2 ? cnt : K + 2;
+                    uint32_t past = keys[kPre - 1];
+#pragma unroll
+                    for (int j = 2; j < kPre - 1; ++j) past = (j == K + 2) ? keys[j] : past;
+                    if (cnt > K + 2 && (past | kSlotMask) == kth) {
+                        giveup = true;
+                        tau = -1.f;
+                    }
+                    uint16_t o[kPre - 1];
+#pragma unroll
+                    for (int j = 0; j < kPre - 1; ++j) o[j] = ring[(keys[j] & kSlotMask) * kBrickThreads];
+#pragma unroll
+                    for (int j = 0; j < kPre - 1; ++j)
+                        if (j < keep) ring[j * kBrickThreads] = o[j];
+                    cnt = giveup ? 0 : keep;
+                } else
                 ring_compact(pts, ring, cnt, tau, qp.x, qp.y, qp.z);
                 if (cnt > NB - SCAN_U) { // ring still full (mass tie): give up, the wave kernel takes it
                     giveup = true;
@@ -690,23 +755,42 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
                 }
             } else if (MODE == 0) {
                 if (!fallback) {
-                    // survivors: exactly K entries with d2 <= cut; canonical order by 64-bit key
-                    ring_compact(pts, ring, cnt, u2f(kth), qp.x, qp.y, qp.z);
-                    uint64_t k[32];
+                    // the row = the first K entries of the sorted prefix; their exact (d2, id) through the low key bits
+                    constexpr int KR = KT > 0 ? KT : kFastKMax - 1;
+                    float dd[KR];
+                    int32_t ii[KR];
+                    bool risky = false;
 #pragma unroll
-                    for (int j = 0; j < 32; ++j) {
-                        const float4 c = lds_pt(pts, ring[(j < cnt ? j : 0) * kBrickThreads]);
-                        const uint32_t d = f2u(dist2<float>(qp.x, qp.y, qp.z, c.x, c.y, c.z));
-                        k[j] = j < cnt ? (((uint64_t)d << 32) | (uint32_t)w_to_id(c.w)) : ~0ull;
+                    for (int j = 0; j < KR; ++j) {
+                        const float4 c = lds_pt(pts, ring[(keys[j] & kSlotMask) * kBrickThreads]);
+                        dd[j] = dist2<float>(qp.x, qp.y, qp.z, c.x, c.y, c.z);
+                        ii[j] = w_to_id(c.w);
+                        if (j + 1 < KR) risky = risky || ((j + 1 < K) && ((keys[j] ^ keys[j + 1]) <= kSlotMask));
+                        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0); // four look-ups in flight, not all of them (registers)
                     }
-                    WTP_SORTNET_32(k)
+                    // entries that share a bucket may be out of order: exact (d2, id) exchange passes until none moves
+                    bool again = risky;
+                    while (__any(again)) {
+                        again = false;
+#pragma unroll
+                        for (int j = 0; j + 1 < KR; ++j) {
+                            const bool sw = (j + 1 < K) && lex_lt(dd[j + 1], ii[j + 1], dd[j], ii[j]);
+                            const float td = dd[j];
+                            const int32_t ti = ii[j];
+                            dd[j] = sw ? dd[j + 1] : td;
+                            ii[j] = sw ? ii[j + 1] : ti;
+                            dd[j + 1] = sw ? td : dd[j + 1];
+                            ii[j + 1] = sw ? ti : ii[j + 1];
+                            again = again || sw;
+                        }
+                    }
                     int32_t* orow = a.idx_out + (int64_t)qid * K;
                     float* drow = a.dist_out ? a.dist_out + (int64_t)qid * K : nullptr;
 #pragma unroll
-                    for (int j = 0; j < kFastKMax; ++j) {
+                    for (int j = 0; j < KR; ++j) {
                         if (j < K) {
-                            orow[j] = (int32_t)(uint32_t)k[j];
-                            if (drow) drow[j] = wsqrt(u2f((uint32_t)(k[j] >> 32)));
+                            orow[j] = ii[j];
+                            if (drow) drow[j] = wsqrt(dd[j]);
                         }
                     }
                 }
@@ -783,7 +867,7 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
             DIAG_STAMP(5) // force / topology sort + outputs
         }
     }
-    if (WTP_DIAG && (tid & 63) == 0) {
+    if (WTP_DIAG && a.diag && (tid & 63) == 0) {
         for (int i = 0; i < 7; ++i) atomicAdd(&a.diag[i], dt[i]);
         atomicAdd(&a.diag[7], 1ull);
     }

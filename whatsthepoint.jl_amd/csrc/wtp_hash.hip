@@ -267,21 +267,6 @@ __global__ void scan_reduce_kernel(const int32_t* __restrict__ cnt, const Grid<T
 }
 
 template <typename T>
-__global__ void scan_top_kernel(int32_t* __restrict__ block_sums, const Grid<T>* __restrict__ gp) {
-    __shared__ int sm[kThreads / 64 + 1];
-    int nblocks = (gp->ncells + kScanTile - 1) / kScanTile;
-    int carry = 0;
-    for (int base = 0; base < nblocks; base += kThreads) {
-        int idx = base + threadIdx.x;
-        int v = idx < nblocks ? block_sums[idx] : 0;
-        int total;
-        int ex = block_excl_scan(v, &total, sm);
-        if (idx < nblocks) block_sums[idx] = carry + ex;
-        carry += total;
-    }
-}
-
-template <typename T>
 __global__ void scan_apply_kernel(int32_t* __restrict__ cnt, const int32_t* __restrict__ block_sums,
                                   const Grid<T>* __restrict__ gp, int32_t* __restrict__ cell_start,
                                   const int32_t* __restrict__ stop) {
@@ -315,8 +300,14 @@ __global__ void scan_apply_kernel(int32_t* __restrict__ cnt, const int32_t* __re
             s += v[j];
         }
     }
+    // offset of this tile = sum of the tile sums in front of it (what a separate single-block scan kernel used to
+    // produce: one launch less, and the sums are a few KB in L2)
+    int front = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += kThreads) front += block_sums[b];
+    int front_total;
+    block_excl_scan(front, &front_total, sm);
     int total;
-    int ex = block_excl_scan(s, &total, sm) + block_sums[blockIdx.x];
+    int ex = block_excl_scan(s, &total, sm) + front_total;
     if (whole) {
         int4* dst = reinterpret_cast<int4*>(cell_start + base + threadIdx.x * kScanItems);
 #pragma unroll
@@ -753,7 +744,6 @@ int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, in
     hipLaunchKernelGGL(cell_rank_kernel<T>, dim3(nb), dim3(kThreads), 0, st, in, n_in, g, cnt, cr, dirty, v_old, v_fixed_old,
                        ctx->stop_dev);
     hipLaunchKernelGGL(scan_reduce_kernel<T>, dim3(nscan), dim3(kThreads), 0, st, cnt, g, bs);
-    hipLaunchKernelGGL(scan_top_kernel<T>, dim3(1), dim3(kThreads), 0, st, bs, g);
     hipLaunchKernelGGL(scan_apply_kernel<T>, dim3(nscan), dim3(kThreads), 0, st, cnt, bs, g, start, ctx->stop_dev);
     hipLaunchKernelGGL(scatter_kernel<T>, dim3(nb), dim3(kThreads), 0, st, in, n_in, cr, g, start, out, v_old, v_fixed_old,
                        v_shift, ctx->stop_dev);

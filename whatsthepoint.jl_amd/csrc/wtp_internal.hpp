@@ -265,13 +265,15 @@ struct wtp_ctx {
     bool rad_offsets_dev = false; // wtp_radius_offsets left the CSR offsets in dist_out (device): fill may take them from there
     wtp::RelaxState relax;
     // timers
-    bool timing = true;
+    bool timing = false;      // per-phase event pairs around every step: off until wtp_timers_reset asks for them (6 event records per step are a third of a small cloud's step)
+    bool timing_forced = false; // WTP_TIMING in the environment decides, wtp_timers_reset does not
     double t_hash = 0, t_sweep = 0, t_other = 0;
     int64_t n_sweep_launches = 0;
     std::vector<hipEvent_t> ev_pool;
     struct Span { int a, b, kind; };
     std::vector<Span> spans;
     int ev_used = 0;
+    int ev_last_end = -1;     // the event that closed the latest span: the next span starts from it (no second record)
 };
 
 namespace wtp {
