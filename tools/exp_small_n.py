@@ -17,10 +17,11 @@ for n in (2000, 10000, 46786, 200000, 1000000, 4000000):
             ctx.timers_reset()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        iters = 200
+        iters = int(os.environ.get("ITERS", "200"))
         t.run_async_free(iters, 1)
+        t_enq = (time.perf_counter() - t0) / iters
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / iters
         tm = ctx.timers() if timers else dict(hash_ms=0.0, sweep_ms=0.0, other_ms=0.0)
         dev = (tm["hash_ms"] + tm["sweep_ms"] + tm["other_ms"]) / iters
-        print(f"n={n:8d}  wall {dt*1e6:8.1f} us/step   device spans {dev*1e3:8.1f} us/step   {n/dt/1e6:8.1f} Mpts/s", flush=True)
+        print(f"n={n:8d}  wall {dt*1e6:8.1f} us/step   device spans {dev*1e3:8.1f} us/step   {n/dt/1e6:8.1f} Mpts/s   host enqueue {t_enq*1e6:6.1f} us/step", flush=True)

@@ -1174,9 +1174,14 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
     a.stop = ctx->stop_dev;
     a.nn_list = nullptr;
     a.nn_count = (int32_t*)ctx->fb_count.p + 2;
-    if (r.cs_sweep && r.cs2_bx > 0) {
+    const bool ball = r.cs_sweep && sizeof(T) == 4 && r.spacing_kind != WTP_SPACING_CONSTANT; // wtp_cs2.hip: cs_ball_kernel
+    if (r.cs_sweep && (r.cs2_bx > 0 || ball)) {
         if ((rc = ensure(ctx, ctx->nn_list, sizeof(int32_t) * (size_t)r.n))) return rc;
         a.nn_list = (int32_t*)ctx->nn_list.p;
+    }
+    if (ball) { // the follow-up kernel has consumed the list by the time the ball kernel refills it
+        a.ball_list = (int32_t*)ctx->nn_list.p;
+        a.ball_count = (int32_t*)ctx->fb_count.p + 6;
     }
     if ((rc = ensure(ctx, ctx->diag, 128))) return rc;
     a.diag = (unsigned long long*)ctx->diag.p;
@@ -1194,7 +1199,23 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
     if (!ctx->counters_clean) WTP_HIP(ctx, hipMemsetAsync(ctx->fb_count.p, 0, 64, ctx->stream));
     ctx->counters_clean = false; // (set again by the step's final reduction, which zeroes the block after reading it)
     a.used_brick = a.used_wave = a.used_generic = 0;
+    // without the wall rule nothing follows the sweep's last kernel: its last block does the final reduction
+    const bool fused_reduce = !r.wall_active;
+    if (fused_reduce) {
+        a.reduce_out = d_slot;
+        a.reduce_wave_base = brick_partials();
+        a.reduce_counters = (int32_t*)ctx->fb_count.p;
+    }
     if ((rc = launch_sweep<T>(ctx, a, fresh))) return rc;
+    if (fused_reduce) {
+        ctx->counters_clean = true;
+        r.bufOld = r.bufP; // p_old (src/repel.jl:244)
+        r.bufP = o;
+        r.can_revert = true;
+        r.have_point_data = true;
+        r.sweeps_since_rebuild += 1;
+        return WTP_OK;
+    }
     int sp = span_begin(ctx, 2);
     if (r.wall_active) { // p[id] = constrain(id, x_i, x_i + disp) (src/repel.jl:290): the octree wall rule
         char* wf = (char*)ctx->wall_flags.p;

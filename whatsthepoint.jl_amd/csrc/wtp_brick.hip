@@ -899,7 +899,7 @@ template <int MODE, int KT, int CS> static int brick_launch(wtp_ctx* ctx, Search
     return WTP_OK;
 }
 
-int brick_partials() { return 1024 + 8 + 512; } // bricks, then the follow-up kernel of the round-2 sweep (wtp_cs2.hip) // + the follow-up kernel of the round-2 sweep (wtp_cs2.hip)
+int brick_partials() { return 1024 + 8 + 512 + 512; } // bricks, then the follow-up kernel of the round-2 sweep (wtp_cs2.hip) // + the follow-up kernel of the round-2 sweep (wtp_cs2.hip)
 
 // RadiusTopology through the brick kernel (fp32): rows of up to 32 entries are counted / sorted and written
 // here, the rest (longer rows, queries the 27 cells cannot certify, bricks too large for LDS) is appended
@@ -945,6 +945,8 @@ template <> int launch_sweep<float>(wtp_ctx* ctx, SearchArgs<float>& a, bool fre
     if (rc) return rc;
     const int sp2 = span_begin(ctx, 2);
     if (cs && a.cs2_bx > 0) rc = launch_cs2_followup(ctx, a); // nearest neighbour of the queries the bricks left open
+    // variable spacing: hand-backs whose support outgrew their cell are finished ball by ball (wtp_cs2.hip)
+    if (!rc && cs && a.spacing_pp && a.ball_list) rc = launch_cs_ball(ctx, a, a.ball_list, a.ball_count);
     if (!rc) rc = launch_generic_sweep<float>(ctx, a, false);
     span_end(ctx, sp2);
     return rc;

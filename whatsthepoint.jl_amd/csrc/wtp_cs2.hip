@@ -793,6 +793,155 @@ __global__ __launch_bounds__(kNnFixThreads, 8) void cs2_nnfix_kernel(SearchArgs<
     if (threadIdx.x == 0) acc_store(&a.partials[part_base + blockIdx.x], acc);
 }
 
+// ---- hand-backs whose support is wider than their cell (variable spacing: the cells follow the spacing a TYPICAL
+// point asks for, the coarse part of a graded cloud asks for more) ------------------------------------------
+// The compact-support argument needs no brick: the ball of radius u0*s around the query, searched in the block of
+// (2R+1)^3 cells that provably contains it (R <= 4), holds n_lim <= k points -> they are the k-set's contributing
+// part and the sum over them is the reference's sum (src/repel.jl:270-280, src/repel_forces.jl:96-100).  Sixteen
+// lanes per query, four queries per wave, one x-row of the block per lane at a time; no LDS, so many waves are in
+// flight and the chain of dependent loads (spacing, row bounds, points) overlaps across queries.  The exact
+// wave-per-query path took 7 ns for each of these (16 % of a 64x-graded cloud: 1.15 of 1.58 ms per iteration).
+// What this kernel cannot certify either — more than k points in the ball, a coincident neighbour, a support wider
+// than four cells, an empty ball whose nearest neighbour the block does not certify — moves on to that path.
+constexpr int kBallThreads = 256;
+constexpr int kBallBlocksMax = 512;
+constexpr int kBallRMax = 4;
+__global__ __launch_bounds__(kBallThreads) void cs_ball_kernel(SearchArgs<float> a, const int32_t* __restrict__ list,
+                                                               const int32_t* __restrict__ list_count,
+                                                               int32_t* __restrict__ out_list, int32_t* __restrict__ out_count,
+                                                               int part_base) {
+    if (a.stop && *a.stop) return; // wtp_relax_run_until: a stop rule fired earlier in this batch
+    __shared__ Acc sacc[kBallThreads / 64];
+    const Grid<float> g = *a.grid;
+    const int n = *list_count;
+    const int K = a.k;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane >> 4, l16 = lane & 15;
+    const int wave_g = (blockIdx.x * kBallThreads + threadIdx.x) >> 6, nwaves = (gridDim.x * kBallThreads) >> 6;
+    const ForceCoefCs fc = force_coef_cs(a.beta, a.u0);
+    Acc acc = acc_empty();
+    for (int i0 = wave_g * 4; i0 < n; i0 += nwaves * 4) {
+        const int i = i0 + grp;
+        const bool on = i < n;
+        const int gslot = list[on ? i : i0];
+        const float4 qp = a.snap[gslot];
+        const int32_t qid = w_to_id(qp.w);
+        const float s = a.spacing_pp ? a.spacing_pp[qid] : a.spacing_const;
+        const float inv_s2 = 1.f / (s * s);
+        const float lim = (a.u0 * a.u0) * (s * s);
+        const int cx = cell_coord(g, qp.x, 0), cy = cell_coord(g, qp.y, 1), cz = cell_coord(g, qp.z, 2);
+        // smallest block that provably holds the ball
+        int R = 0;
+        float g2 = 0.f;
+#pragma unroll
+        for (int r = 1; r <= kBallRMax; ++r) {
+            const float t = safe_radius2(g, qp.x, qp.y, qp.z, cx, cy, cz, r);
+            const bool take = R == 0 && lim <= t;
+            g2 = take ? t : g2;
+            R = take ? r : R;
+        }
+        const bool ok = on && R > 0;
+        const int side = 2 * R + 1, nrows = ok ? side * side : 0;
+        const int x0 = cx - R < 0 ? 0 : cx - R, x1 = cx + R > g.n[0] - 1 ? g.n[0] - 1 : cx + R;
+        int n_lim = 0;
+        bool coincident = false;
+        float Fx = 0.f, Fy = 0.f, Fz = 0.f;
+        int32_t nid = 0x7FFFFFFF;
+        float nd2 = Lim<float>::inf();
+        // a lane's rows (at most six of the 81): all bounds first, then the points four loads at a time — the loop is a
+        // chain of global round trips otherwise (one per point: 3.7 ns per query measured, 161 k queries 0.6 ms)
+        constexpr int kRowsPerLane = ((2 * kBallRMax + 1) * (2 * kBallRMax + 1) + 15) / 16;
+        int ps[kRowsPerLane], pe[kRowsPerLane];
+#pragma unroll
+        for (int j = 0; j < kRowsPerLane; ++j) {
+            const int row = l16 + 16 * j;
+            const int y = cy + row % side - R, z = cz + row / side - R;
+            const bool in = row < nrows && y >= 0 && y < g.n[1] && z >= 0 && z < g.n[2];
+            const int base = in ? (z * g.n[1] + y) * g.n[0] : 0;
+            ps[j] = a.cell_start[base + (in ? x0 : 0)];
+            pe[j] = in ? a.cell_start[base + x1 + 1] : ps[j]; // (an absent row: empty)
+        }
+        auto visit = [&](const float4& c, bool valid) {
+            const float dx = qp.x - c.x, dy = qp.y - c.y, dz = qp.z - c.z;
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            const int32_t cid = w_to_id(c.w);
+            const bool inl = valid && d <= lim;
+            n_lim += inl ? 1 : 0;
+            const bool other = valid && cid != qid; // self skipped by index (src/repel.jl:271)
+            const bool nearer = other && lex_lt(d, cid, nd2, nid);
+            nd2 = nearer ? d : nd2;
+            nid = nearer ? cid : nid;
+            const bool act = inl && other;
+            const float f = force_fast_cs(fc, d * inv_s2);
+            const float coef = (act && d > 0.f) ? f * __builtin_amdgcn_rsqf(d) : 0.f;
+            Fx = __builtin_fmaf(coef, dx, Fx);
+            Fy = __builtin_fmaf(coef, dy, Fy);
+            Fz = __builtin_fmaf(coef, dz, Fz);
+            coincident = coincident || (act && !(d > 0.f));
+        };
+#pragma unroll
+        for (int j = 0; j < kRowsPerLane; ++j) {
+            for (int p = ps[j]; p < pe[j]; p += 4) {
+                float4 c[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) c[u] = a.snap[p + u < pe[j] ? p + u : p];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) visit(c[u], p + u < pe[j]);
+            }
+        }
+        // the sixteen lanes of the query: sums in a fixed order, lexicographic minimum
+#pragma unroll
+        for (int dlt = 8; dlt >= 1; dlt >>= 1) {
+            Fx += __shfl_xor(Fx, dlt, 64);
+            Fy += __shfl_xor(Fy, dlt, 64);
+            Fz += __shfl_xor(Fz, dlt, 64);
+            n_lim += __shfl_xor(n_lim, dlt, 64);
+            coincident = coincident || (__shfl_xor((int)coincident, dlt, 64) != 0);
+            const float od = __shfl_xor(nd2, dlt, 64);
+            const int32_t oi = __shfl_xor(nid, dlt, 64);
+            if (lex_lt(od, oi, nd2, nid)) {
+                nd2 = od;
+                nid = oi;
+            }
+        }
+        if (l16 == 0 && on) {
+            // nearest neighbour: inside the ball it is the global one; outside it must lie within the radius the
+            // block is complete for
+            const bool nn_ok = nid != 0x7FFFFFFF && (nd2 <= lim || nd2 <= g2);
+            if (!ok || n_lim > K || coincident || !nn_ok || qid < a.n_fixed) {
+                const int pos = atomicAdd(out_count, 1);
+                out_list[pos] = gslot;
+            } else {
+                float4 o;
+                const float f = cs_step_point(a, s, qp.x, qp.y, qp.z, Fx, Fy, Fz, o.x, o.y, o.z);
+                o.w = qp.w;
+                a.out[gslot] = o;
+                a.forces[gslot] = f;
+                const float nd = wsqrt(nd2);
+                if (reaches_past_cover<float>(a, qp.x, qp.y, qp.z, nd2 > lim ? nd2 : lim)) atomicAdd(a.uncovered, 1);
+                a.nn_dist[gslot] = nd;
+                a.nn_id[gslot] = nid;
+                acc_point<float>(acc, f, nd, s, qid, nid);
+            }
+        }
+    }
+    acc_block_reduce(acc, sacc);
+    if (threadIdx.x == 0) acc_store(&a.partials[part_base + blockIdx.x], acc);
+}
+
+// Runs between the brick kernels' follow-up and the exact path; on return a.fb_list / a.fb_count name what is left.
+int launch_cs_ball(wtp_ctx* ctx, SearchArgs<float>& a, int32_t* rest_list, int32_t* rest_count) {
+    int blocks = (int)((a.n + 1023) / 1024);
+    blocks = blocks < 8 ? 8 : (blocks > kBallBlocksMax ? kBallBlocksMax : blocks);
+    hipLaunchKernelGGL(cs_ball_kernel, dim3(blocks), dim3(kBallThreads), 0, ctx->stream, a, (const int32_t*)a.fb_list,
+                       (const int32_t*)a.fb_count, rest_list, rest_count, a.used_brick);
+    a.used_brick += blocks;
+    a.fb_list = rest_list;
+    a.fb_count = rest_count;
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
 int launch_cs2(wtp_ctx* ctx, SearchArgs<float>& a) {
     const int hcap = a.brick_hcap, BX = a.cs2_bx;
     if (hcap < 64 || hcap > 4096 || BX < 1 || BX > kCsMaxBX)

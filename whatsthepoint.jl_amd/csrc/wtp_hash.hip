@@ -963,40 +963,8 @@ __global__ void reduce_partials_kernel(const Partial* __restrict__ parts, int n_
                                        const int32_t* __restrict__ uncovered, const int32_t* __restrict__ escaped,
                                        wtp_step_stats* __restrict__ out, int32_t* __restrict__ counters) {
     __shared__ Acc sm[kThreads / 64];
-    Acc acc = acc_empty();
-    // only the slots this step's launches wrote (fixed order => deterministic): three ranges
-    const int total = used_brick + used_wave + used_generic;
-    for (int t = threadIdx.x; t < total; t += blockDim.x) {
-        const int i = t < used_brick ? t
-                                     : (t < used_brick + used_wave ? wave_base + (t - used_brick)
-                                                                   : n_parts - kGenericPartials + (t - used_brick - used_wave));
-        if (parts[i].n_move == 0) continue; // slot of a block that saw no movable point
-        Acc o;
-        o.max_force = parts[i].max_force;
-        o.sum_u = parts[i].sum_u;
-        o.sum_u2 = parts[i].sum_u2;
-        o.argmin_r = parts[i].argmin_r;
-        o.argmin_i = parts[i].argmin_i;
-        o.argmin_j = parts[i].argmin_j;
-        o.n_move = parts[i].n_move;
-        acc_merge(acc, o);
-    }
-    acc_block_reduce(acc, sm);
-    if (threadIdx.x == 0) {
-        out->max_force = acc.max_force;
-        out->sum_u = acc.sum_u;
-        out->sum_u2 = acc.sum_u2;
-        out->n_move = acc.n_move;
-        out->argmin_i = acc.argmin_i;
-        out->argmin_j = acc.argmin_j;
-        out->argmin_r = acc.argmin_r;
-        out->n_fallback = fb_count ? *fb_count : 0;
-        out->n_uncovered = uncovered ? *uncovered : 0;
-        out->n_escaped = escaped ? *escaped : 0;
-    }
-    // the step's counter block (hand-backs, uncovered, escaped, ...) has been read: all-zero for the next step
-    __syncthreads();
-    if (counters && threadIdx.x < 16) counters[threadIdx.x] = 0;
+    reduce_partials_block(parts, n_parts, used_brick, wave_base, used_wave, used_generic, fb_count, uncovered, escaped, out,
+                          counters, sm);
 }
 
 int launch_reduce_partials(wtp_ctx* ctx, const Partial* parts, int n_parts, int used_brick, int used_wave,

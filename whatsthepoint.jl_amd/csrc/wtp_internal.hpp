@@ -108,6 +108,11 @@ template <typename T> struct SearchArgs {
     // blocks each sweep kernel was launched with = partial slots it wrote (set by the launchers):
     // brick [0, used_brick), wave [brick_partials(), +used_wave), serial [n_partials - kGenericPartials, +used_generic)
     int32_t used_brick, used_wave, used_generic;
+    // the step's final reduction rides in the last block of the serial kernel (one launch less) when the caller
+    // sets these: stats slot, wave partial base, counter block (ticket in [14]; zeroed after use), escaped counter
+    wtp_step_stats* reduce_out;
+    int32_t reduce_wave_base;
+    int32_t* reduce_counters;
     // RadiusTopology through the brick kernel: r^2, row lengths out (count phase) or row starts in (fill phase)
     T radius2;
     int32_t* rad_counts;
@@ -120,6 +125,8 @@ template <typename T> struct SearchArgs {
     int32_t* fb2_count;
     int32_t* nn_list;          // round-2 sweep: queries whose nearest neighbour the follow-up kernel still has to find
     int32_t* nn_count;
+    int32_t* ball_list;        // what the ball kernel (variable-spacing hand-backs) leaves for the exact path, and its count
+    int32_t* ball_count;
     const int32_t* stop;       // wtp_relax_run_until: non-zero once a stop rule has fired; later sweeps of the batch do nothing
     // sharded sessions: the snapshot is complete only for cover_lo <= coord[cover_axis] <= cover_hi;
     // queries whose neighbourhood reaches past that range are counted (wtp_relax_set_coverage)
@@ -336,6 +343,7 @@ int launch_brick_radius(wtp_ctx* ctx, SearchArgs<float>& a);
 // round-2 compact-support sweep (wtp_cs2.hip)
 int launch_cs2(wtp_ctx* ctx, SearchArgs<float>& a);
 int launch_cs2_followup(wtp_ctx* ctx, SearchArgs<float>& a);
+int launch_cs_ball(wtp_ctx* ctx, SearchArgs<float>& a, int32_t* rest_list, int32_t* rest_count);
 int launch_cs2_census(wtp_ctx* ctx, int BX, unsigned int* d_out513);
 int cs2_max_bx();
 template <typename T>
