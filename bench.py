@@ -259,7 +259,8 @@ def _graded_legs(out, ctx, np, wtp_amd, time):
         "value": round(ng / dt / 1e6, 1), "unit": "Mpoints/s", "ms_per_iter": round(dt * 1e3, 3),
         "exact_path_fraction": round(st["n_fallback"] / ng, 4),
         "note": "64x density contrast; cell edge measured from the occupancy; points whose support exceeds a cell "
-                "take the exact wave-per-query path, which dominates the time (DESIGN.md §4)"}
+                "are finished by the ball kernel (wtp_cs2.hip), the rest (exact_path_fraction) by the wave-per-query path; "
+                "the law itself (1-NN in the boundary kd-tree, every sweep) is now the largest piece (DESIGN.md §4)"}
     ctx.timers_reset()
     t0 = time.perf_counter()
     off, _ = ctx.radius(xg, 2.5 * hw)
