@@ -1133,9 +1133,11 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
         // s = spacing(x_i) at the point's current position (src/repel.jl:251 on rebuilds, :260 in every
         // sweep): the movable tail is re-evaluated before each sweep, the wall keeps its setup values
         int sps = span_begin(ctx, 2);
+        // (the slot order of P is the sorted order of the last rebuild: the grid groups the points of a wave compactly)
         rc = launch_spacing_session<T>(ctx, (const Pt<T>*)ctx->pts[r.bufP].p, r.n, r.n_fixed, ctx->kd_nodes.p, ctx->kd_m,
                                        r.spacing_kind, r.sp_p0, r.sp_p1, r.sp_p2, (T*)ctx->spacing_pp.p,
-                                       (int32_t*)ctx->sp_hint.p);
+                                       (int32_t*)ctx->sp_hint.p, r.have_tree ? (const int32_t*)ctx->cell_start.p : nullptr,
+                                       ctx->grid.p);
         span_end(ctx, sps);
         if (rc) return rc;
     }

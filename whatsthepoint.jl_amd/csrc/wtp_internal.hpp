@@ -384,7 +384,8 @@ int launch_spacing_eval(wtp_ctx* ctx, const T* d_xyz, int64_t n, int dim, const 
                         double p0, double p1, double p2, T* d_out);
 template <typename T>
 int launch_spacing_session(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int64_t first_id, const void* d_nodes, int64_t m,
-                           int kind, double p0, double p1, double p2, T* d_spacing_pp, int32_t* d_hint);
+                           int kind, double p0, double p1, double p2, T* d_spacing_pp, int32_t* d_hint,
+                           const int32_t* d_cell_start = nullptr, const void* d_grid = nullptr);
 // fp64 topology through an fp32 candidate search (wtp_hash.hip)
 int launch_origin(wtp_ctx* ctx, const double4* pts, int64_t n, double* d_org4);
 int launch_to_local_f32(wtp_ctx* ctx, const double4* in, int64_t n, const double* d_org4, float4* out);

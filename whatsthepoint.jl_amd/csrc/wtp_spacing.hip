@@ -210,20 +210,26 @@ __global__ void spacing_eval_kernel(const T* __restrict__ xyz, int64_t n, int di
 }
 
 // Session points (slot order, id in w) -> spacing_pp[id]; ids below first_id keep their value.
+//
+// Which 64 points walk the tree together decides how long the walk is (a wave visits the union of what its lanes
+// want).  Consecutive slots are one x-row of cells — with the round-2 sweep's one-point cells a wave would be a line
+// 64 cells long, and next to a finely sampled wall the union of 64 such searches is several hundred nodes.  With
+// the grid at hand the wave takes a compact tile instead: W x H x H cells, as cubic as the mean occupancy allows and
+// ~56 points, its row segments (one per lane) enumerated through cell_start.  The grouping only affects speed: every lane still gets the
+// minimum over ALL boundary points.
 template <typename T>
 __global__ void spacing_session_kernel(const Pt<T>* __restrict__ pts, int64_t n, int32_t first_id,
                                        const KdNode<T>* __restrict__ nodes, int32_t m, SpacingLaw<T> law,
                                        T* __restrict__ spacing_pp, int32_t* __restrict__ hint,
-                                       const int32_t* __restrict__ stop) {
+                                       const int32_t* __restrict__ stop, const int32_t* __restrict__ cell_start,
+                                       const Grid<T>* __restrict__ gp) {
     __shared__ int32_t kd_stack[kSpThreads / 64][64];
     if (stop && *stop) return;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t span = (n + 63) / 64 * 64; // whole waves walk the tree together
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < span; i += stride) {
-        const Pt<T> p = pts[i < n ? i : n - 1];
+    auto one = [&](int64_t slot, bool on) {
+        const Pt<T> p = pts[on ? slot : 0];
         const int32_t id = w_to_id(p.w);
-        const bool active = i < n && id >= first_id;
-        if (!__any(active)) continue;
+        const bool active = on && id >= first_id;
+        if (!__any(active)) return;
         int32_t bn;
         const T d2 = kd_nearest_d2<T>(nodes, m, p.x, p.y, p.z, active, active ? hint[id] : -1, &bn,
                                       kd_stack[threadIdx.x >> 6]);
@@ -231,6 +237,60 @@ __global__ void spacing_session_kernel(const Pt<T>* __restrict__ pts, int64_t n,
             spacing_pp[id] = spacing_law<T>(law, wsqrt(d2));
             hint[id] = bn; // points move a fraction of a spacing per sweep: next time this is (nearly) the answer
         }
+    };
+    if (!cell_start) { // no grid yet (session setup): slot order
+        const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+        const int64_t span = (n + 63) / 64 * 64; // whole waves walk the tree together
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < span; i += stride) one(i, i < n);
+        return;
+    }
+    const Grid<T> g = *gp;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // tile = W x H x Hz cells, as cubic as the occupancy allows and ~56 points: up to 64 row segments, one per lane
+    const float rho0 = (float)g.npts / (float)(g.ncells > 0 ? g.ncells : 1);
+    const float rho = rho0 > 0.125f ? rho0 : 0.125f;
+    const bool flat = g.n[2] <= 1;
+    int H = (int)(flat ? sqrtf(56.f / rho) : cbrtf(56.f / rho) + 0.5f);
+    H = H < 1 ? 1 : (H > 8 ? 8 : H);
+    const int Hz = flat ? 1 : H;
+    int W = (int)(56.f / (rho * (float)(H * Hz)) + 0.5f);
+    W = W < 1 ? 1 : (W > 32 ? 32 : W);
+    const int nrow = H * Hz; // <= 64
+    const int tx_n = (g.n[0] + W - 1) / W, ty_n = (g.n[1] + H - 1) / H, tz_n = (g.n[2] + Hz - 1) / Hz;
+    const int64_t ntiles = (int64_t)tx_n * ty_n * tz_n;
+    const int64_t wave_g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    __shared__ int32_t row_end[kSpThreads / 64][64], row_start[kSpThreads / 64][64];
+    for (int64_t t = wave_g; t < ntiles; t += nwaves) {
+        const int tx = (int)(t % tx_n), ty = (int)((t / tx_n) % ty_n), tz = (int)(t / ((int64_t)tx_n * ty_n));
+        const int x0 = tx * W, x1 = (x0 + W) < g.n[0] ? (x0 + W) : g.n[0];
+        // lane r < nrow: its row segment of the tile
+        const int y = ty * H + lane % H, z = tz * Hz + lane / H;
+        const bool in = lane < nrow && y < g.n[1] && z < g.n[2];
+        const int base = in ? (z * g.n[1] + y) * g.n[0] : 0;
+        const int s0 = cell_start[base + (in ? x0 : 0)];
+        const int len = in ? cell_start[base + x1] - s0 : 0;
+        int incl = len;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        const int total = __shfl(incl, 63, 64);
+        __builtin_amdgcn_wave_barrier();
+        row_end[wave][lane] = incl;
+        row_start[wave][lane] = s0 - (incl - len); // slot = row_start + tile-local index
+        __builtin_amdgcn_wave_barrier();
+        for (int b = 0; b < total; b += 64) {
+            const int i = b + lane;
+            const bool on = i < total;
+            // first row whose inclusive end exceeds i
+            int lo = 0;
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) lo += (row_end[wave][lo + step - 1] <= i) ? step : 0;
+            lo = lo > 63 ? 63 : lo;
+            one((int64_t)row_start[wave][lo] + i, on);
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -251,10 +311,12 @@ int launch_spacing_eval(wtp_ctx* ctx, const T* d_xyz, int64_t n, int dim, const 
 
 template <typename T>
 int launch_spacing_session(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int64_t first_id, const void* d_nodes, int64_t m,
-                           int kind, double p0, double p1, double p2, T* d_spacing_pp, int32_t* d_hint) {
+                           int kind, double p0, double p1, double p2, T* d_spacing_pp, int32_t* d_hint,
+                           const int32_t* d_cell_start, const void* d_grid) {
     SpacingLaw<T> law{kind, (T)p0, (T)p1, (T)p2};
     hipLaunchKernelGGL(spacing_session_kernel<T>, dim3(sp_grid(n)), dim3(kSpThreads), 0, ctx->stream, pts, n,
-                       (int32_t)first_id, (const KdNode<T>*)d_nodes, (int32_t)m, law, d_spacing_pp, d_hint, ctx->stop_dev);
+                       (int32_t)first_id, (const KdNode<T>*)d_nodes, (int32_t)m, law, d_spacing_pp, d_hint, ctx->stop_dev,
+                       d_cell_start, (const Grid<T>*)d_grid);
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;
 }
@@ -265,7 +327,7 @@ int launch_spacing_session(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int64_t fi
     template int launch_spacing_eval<T>(wtp_ctx*, const T*, int64_t, int, const void*, int64_t, int, double, \
                                         double, double, T*);                                                 \
     template int launch_spacing_session<T>(wtp_ctx*, const Pt<T>*, int64_t, int64_t, const void*, int64_t, int, \
-                                           double, double, double, T*, int32_t*);
+                                           double, double, double, T*, int32_t*, const int32_t*, const void*);
 INST(float)
 INST(double)
 #undef INST
