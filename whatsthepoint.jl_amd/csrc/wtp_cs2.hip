@@ -265,6 +265,7 @@ __global__ __launch_bounds__(kCsThreads, 4) void cs2_kernel(SearchArgs<float> a,
         const int next = brick + blk_per_group;
         advance(pos_next);
 
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads(); // previous brick's LDS no longer in use
         int vn[4] = {0, 0, 0, 0};
         if (next < b_end) load_cells(pos_next, vn);
@@ -386,6 +387,9 @@ __global__ __launch_bounds__(kCsThreads, 4) void cs2_kernel(SearchArgs<float> a,
             }
             continue;
         }
+        // waves that run queries issue ahead of waves that stage (those mostly wait for loads and barriers anyway):
+        // 653 -> 630 us per launch at 10 M points
+        __builtin_amdgcn_s_setprio(1);
         for (int qb = 0; qb < Q; qb += kCsThreads) {
             const int q = qb + tid;
             const bool active = q < Q;
