@@ -287,19 +287,27 @@ static int knn_dev_t(wtp_ctx* ctx, const T* d_xyz, int64_t n, int dim, int k, in
     // The measured cell scale of the last topology call is reused for a cloud of the same size (the
     // usual case: rebuild_topology! on the same points); it only affects speed, never the result.
     const int kq = include_self ? k : k + 1;
+    ctx->topology_build = true;
     if (ctx->knn_tune_n == n && ctx->knn_tune_dim == dim && ctx->knn_tune_k == kq && !ctx->knn_tune_boxed) {
         ctx->box_active = false;
-        if ((rc = build_hash<T>(ctx, raw, sorted, n, dim, kq, 0.0, 0.0, 0.0, ctx->knn_tune_scale))) return rc;
+        if ((rc = build_hash<T>(ctx, raw, sorted, n, dim, kq, 0.0, 0.0, 0.0, ctx->knn_tune_scale))) {
+            ctx->topology_build = false;
+            return rc;
+        }
     } else {
         double scale = 1.0, rho_eff = 0;
         Grid<T> hg;
-        if ((rc = build_hash_tuned<T>(ctx, raw, sorted, n, dim, kq, 0.0, 0.0, 0.0, &scale, &rho_eff, &hg))) return rc;
+        if ((rc = build_hash_tuned<T>(ctx, raw, sorted, n, dim, kq, 0.0, 0.0, 0.0, &scale, &rho_eff, &hg))) {
+            ctx->topology_build = false;
+            return rc;
+        }
         ctx->knn_tune_n = n;
         ctx->knn_tune_dim = dim;
         ctx->knn_tune_k = kq;
         ctx->knn_tune_scale = scale;
         ctx->knn_tune_boxed = ctx->box_active; // a clipped box belongs to this very cloud: never reuse it
     }
+    ctx->topology_build = false;
     span_end(ctx, sp);
     SearchArgs<T> a{};
     a.grid = (const Grid<T>*)ctx->grid.p;
@@ -365,7 +373,10 @@ static int knn_dev_f64(wtp_ctx* ctx, const double* d_xyz, int64_t n, int dim, in
     if ((rc = launch_to_local_f32(ctx, raw64, n, org4, raw32))) return rc;
     double scale = 1.0, rho_eff = 0;
     Grid<float> hg;
-    if ((rc = build_hash_tuned<float>(ctx, raw32, sorted32, n, dim, kc, 0.0, 0.0, 0.0, &scale, &rho_eff, &hg))) return rc;
+    ctx->topology_build = true;
+    rc = build_hash_tuned<float>(ctx, raw32, sorted32, n, dim, kc, 0.0, 0.0, 0.0, &scale, &rho_eff, &hg);
+    ctx->topology_build = false;
+    if (rc) return rc;
     span_end(ctx, sp);
     ctx->knn_tune_n = -1; // the cached scale belongs to fp32 calls
     SearchArgs<float> a{};
@@ -474,6 +485,7 @@ WTP_API int wtp_create(const int* device_ordinals, int n_dev, wtp_ctx** out) {
     ctx->stream = ctx->own_stream;
     if (const char* e = getenv("WTP_RHO")) ctx->rho = atof(e) > 0 ? atof(e) : ctx->rho;
     if (const char* e = getenv("WTP_GAMMA_CAP")) ctx->gamma_cap = atof(e) > 0 ? atof(e) : ctx->gamma_cap;
+    if (const char* e = getenv("WTP_GAMMA_CAP_SWEEP")) ctx->gamma_cap_sweep = atof(e) > 0 ? atof(e) : ctx->gamma_cap_sweep;
     if (const char* e = getenv("WTP_TNN")) ctx->tnn_frac = atof(e) > 0 && atof(e) < 0.99 ? atof(e) : ctx->tnn_frac;
     if (const char* e = getenv("WTP_FORCE_GENERIC")) ctx->force_generic = atoi(e);
     if (const char* e = getenv("WTP_FULL_SELECT")) ctx->full_select = atoi(e);
@@ -655,7 +667,10 @@ template <typename T> static int radius_count_t(wtp_ctx* ctx, int64_t n, int dim
     int sp = span_begin(ctx, 0);
     if ((rc = load_points<T>(ctx, (const T*)ctx->raw_in.p, raw, n, dim))) return rc;
     ctx->box_active = false;
-    if ((rc = build_hash<T>(ctx, raw, sorted, n, dim, 0, r > 0 ? r : 1e-300))) return rc;
+    ctx->topology_build = true;
+    rc = build_hash<T>(ctx, raw, sorted, n, dim, 0, r > 0 ? r : 1e-300);
+    ctx->topology_build = false;
+    if (rc) return rc;
     span_end(ctx, sp);
     SearchArgs<T> a{};
     a.grid = (const Grid<T>*)ctx->grid.p;
@@ -1049,7 +1064,7 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
         // round-2 sweep (wtp_cs2.hip, fp32 3-D): the nearest neighbour comes from the support or from a
         // per-wave follow-up, so the cells only cover the support: rho ~ 1
         const bool cs2 = r.cs_sweep && ctx->cs2 && sizeof(T) == 4 && r.dim == 3;
-        double rho_cs = r.cs_sweep ? (cs2 ? ctx->rho_cs2 : 3.5 * (ctx->rho / 8.0)) : 0.0;
+        double rho_cs = r.cs_sweep ? (cs2 ? ctx->rho_cs2 : 3.5 * (ctx->rho / 9.0)) : 0.0;
         if (r.spacing_typ <= 0) { // once per session: the spacing a typical point asks for
             r.spacing_typ = r.spacing_const;
             if (r.spacing_kind != WTP_SPACING_CONSTANT) {

@@ -935,7 +935,7 @@ template <> int launch_sweep<float>(wtp_ctx* ctx, SearchArgs<float>& a, bool fre
         span_end(ctx, sp);
         return rc;
     }
-    a.gamma_cap = (float)ctx->gamma_cap;
+    a.gamma_cap = (float)ctx->gamma_cap_sweep;
     const int sp = span_begin(ctx, 1);
     // ClippedSpacingForce (the reference default) takes the compact-support sweep unless
     // WTP_FULL_SELECT=1 asks for the explicit k-selection on every query (both give the same output)

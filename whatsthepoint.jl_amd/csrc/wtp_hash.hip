@@ -747,10 +747,12 @@ int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, in
     hipLaunchKernelGGL(scan_apply_kernel<T>, dim3(nscan), dim3(kThreads), 0, st, cnt, bs, g, start, ctx->stop_dev);
     hipLaunchKernelGGL(scatter_kernel<T>, dim3(nb), dim3(kThreads), 0, st, in, n_in, cr, g, start, out, v_old, v_fixed_old,
                        v_shift, ctx->stop_dev);
-    hipLaunchKernelGGL(canon_kernel<T>, dim3(grid_for((cap + 15) / 16, kThreads, 4096)), dim3(kThreads), 0, st, out, start, dirty,
-                       g, ctx->stop_dev);
+    if (!ctx->topology_build) {
+        hipLaunchKernelGGL(canon_kernel<T>, dim3(grid_for((cap + 15) / 16, kThreads, 4096)), dim3(kThreads), 0, st, out, start,
+                           dirty, g, ctx->stop_dev);
+    }
     WTP_HIP(ctx, hipGetLastError());
-    ctx->hash_scratch_clean = true;
+    ctx->hash_scratch_clean = !ctx->topology_build; // (without the canonical-order pass the dirty marks stay: the next build clears them)
     return WTP_OK;
 }
 

@@ -203,8 +203,9 @@ struct wtp_ctx {
     std::string err;
     int sm_count = 256;
     // tunables (env WTP_RHO / WTP_GAMMA_CAP / WTP_FORCE_GENERIC)
-    double rho = 8.0;
-    double gamma_cap = 1.08;
+    double rho = 9.0;            // WTP_RHO: points per cell of the k = 21 selection grids (round 2: 8 -> 9, fewer hand-backs; measured)
+    double gamma_cap = 1.0;      // WTP_GAMMA_CAP: first filter radius of the topology kernels, in cell edges (round 2: 1.08 -> 1.0, fewer ring prunes)
+    double gamma_cap_sweep = 0.96; // WTP_GAMMA_CAP_SWEEP: the same for the sweep with explicit k-selection (4.28 -> 3.55 ms at 10 M)
     double tnn_frac = 0.8;     // WTP_TNN: measured optimum between candidate volume and isolated-query hand-backs (0.9: 1.55 ms, 0.8: 1.44, 0.7: 1.69 per 10 M step)
     int force_generic = 0;
     int full_select = 0;       // WTP_FULL_SELECT=1: never use the compact-support sweep
@@ -227,6 +228,8 @@ struct wtp_ctx {
     wtp::DevBuf grid, bbox_part, occ;
     wtp::HashView hash_view;   // consumed by the next build_hash call (set and cleared by the caller)
     wtp::DevBuf box_dev;       // robust box {lo xyz, hi xyz} (doubles) + histogram scratch behind it
+    bool topology_build = false; // set around the hash builds of KNN / radius topology calls: their rows are ordered by (d2, id) explicitly, so the
+                                 // within-cell order by id (canon_kernel: 0.3 of a 1.1 ms KNN call on unsorted input) buys nothing there
     bool reuse_grid = false;   // one-shot: the next build_hash keeps the previous Grid (no bounding-box pass)
     int grid_reuse_max = 7;    // WTP_GRID_REUSE: rebuilds of a relax session that may reuse a grid (0 = never)
     bool box_active = false;   // grid_setup clips the bounding box to box_dev (outliers piled into edge cells)
