@@ -321,6 +321,31 @@ int wtp_relax_step_layers3(wtp_ctx* ctx, int rebuild, wtp_step_stats* stats, int
                            const double hi_in[3], const double lo_out[3], const double hi_out[3], void* const d_lo4[3],
                            void* const d_hi4[3], int64_t cap, int64_t counts[12]);
 
+/* ---- the context owns an RCCL communicator ---------------------------------------------------
+ * One process per GPU, one context per process.  With these four calls and the wtp_relax_*_dev / *_layers3 /
+ * set_fixed_dev / set_coverage_box entry points a caller without torch.distributed (the Julia side) runs the block
+ * decomposition of DESIGN.md §7b through the C ABI alone; INTEGRATION.md lists the loop.  librccl is opened with dlopen
+ * at the first call, so single-GPU users never load it.  No counterpart in the reference (it has no multi-GPU path). */
+#define WTP_COMM_ID_BYTES 128
+/* Rank 0 creates the id (ncclGetUniqueId); the caller carries the 128 bytes to the other ranks (MPI, a file, ...). */
+int wtp_comm_unique_id(wtp_ctx* ctx, void* id_out);
+/* Collective over all ranks: ncclCommInitRank on the context's device. */
+int wtp_comm_init(wtp_ctx* ctx, const void* id, int rank, int nranks);
+int wtp_comm_finalize(wtp_ctx* ctx);
+/* One point-to-point round with the low and the high neighbour along an axis (peer = rank, or -1 for none).  Rows are
+ * 16 bytes — the packed {x, y, z, w} fp32 rows wtp_relax_step_layers3 fills and wtp_relax_set_fixed_dev takes.  The
+ * counts travel first, then the rows, all on the context's stream: on return the received counts are known on the
+ * host and the rows are stream-ordered (the next launch on this context sees them).  d_recv_* hold `cap` rows; if a
+ * peer sends more, the rows are dropped, the counts are still returned and the call fails with WTP_ERR_ARG (nobody
+ * is left hanging).  Every rank that names a peer must be named by that peer in the same call. */
+int wtp_comm_exchange_rows(wtp_ctx* ctx, int peer_lo, int peer_hi, const void* d_send_lo, int64_t n_send_lo,
+                           const void* d_send_hi, int64_t n_send_hi, void* d_recv_lo, void* d_recv_hi, int64_t cap,
+                           int64_t* n_recv_lo, int64_t* n_recv_hi);
+/* The global view of a sweep, in place: maximum of max_force; sums of sum_u, sum_u2, n_move, n_fallback, n_uncovered,
+ * n_escaped — what the stop rules of `_relax!` (src/repel.jl:293,305-334) and the ghost-width check read.  argmin_r
+ * becomes the global minimum; argmin_i / argmin_j stay local indices on the rank that holds it and become -1 elsewhere. */
+int wtp_comm_allreduce_stats(wtp_ctx* ctx, wtp_step_stats* stats);
+
 /* Coverage of a sharded session: the caller guarantees that the snapshot holds every point of
  * the global cloud with lo <= coord[axis] <= hi (its slab plus the ghost layers; an end may be
  * +-inf).  A sweep then counts in stats.n_uncovered the movable points whose answer needs more:

@@ -202,6 +202,27 @@ function relax!(p, p_old, snap, spacing, force_model; n_fixed, α_lo, α_max, k,
     return conv
 end
 
+# ---- multi-GPU: the context's RCCL communicator (include/wtp.h: wtp_comm_*; one Julia process per GPU) ------------
+# The caller's own transport carries the id once (MPI.Bcast!, a file); INTEGRATION.md lists the block iteration.
+function comm_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    check(context(), ccall((:wtp_comm_unique_id, lib), Cint, (Ptr{Cvoid}, Ptr{UInt8}), context(), id))
+    return id
+end
+comm_init(id::Vector{UInt8}, rank::Int, nranks::Int) =
+    check(context(), ccall((:wtp_comm_init, lib), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint), context(), id, rank, nranks))
+comm_finalize() = check(context(), ccall((:wtp_comm_finalize, lib), Cint, (Ptr{Cvoid},), context()))
+# device pointers (Ptr{Cvoid}) to packed 16-byte rows; returns the received counts, rows are stream-ordered
+function comm_exchange_rows(peer_lo::Int, peer_hi::Int, send_lo, n_lo::Int, send_hi, n_hi::Int, recv_lo, recv_hi, cap::Int)
+    got_lo = Ref{Int64}(0); got_hi = Ref{Int64}(0)
+    check(context(), ccall((:wtp_comm_exchange_rows, lib), Cint,
+        (Ptr{Cvoid}, Cint, Cint, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ref{Int64}, Ref{Int64}),
+        context(), peer_lo, peer_hi, send_lo, n_lo, send_hi, n_hi, recv_lo, recv_hi, cap, got_lo, got_hi))
+    return got_lo[], got_hi[]
+end
+comm_allreduce_stats!(st::StepStats) =
+    check(context(), ccall((:wtp_comm_allreduce_stats, lib), Cint, (Ptr{Cvoid}, Ref{StepStats}), context(), st))
+
 # ---- set_topology / rebuild_topology! (src/cloud.jl:200-228, src/surface.jl:167-205, src/volume.jl:97-125) ----------
 # The containers stay the reference's; only the adjacency comes from the device.
 knn_topology(pts, k::Int) = WhatsThePoint.KNNTopology(build_knn_neighbors(pts, k), k)

@@ -95,6 +95,11 @@ SIGNATURES = {
                                     C.POINTER(_i64)]),
     "wtp_relax_set_coverage": (_i, [_vp, _i, _d, _d]),
     "wtp_relax_set_coverage_box": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "wtp_comm_unique_id": (_i, [_vp, _vp]),
+    "wtp_comm_init": (_i, [_vp, _vp, _i, _i]),
+    "wtp_comm_finalize": (_i, [_vp]),
+    "wtp_comm_exchange_rows": (_i, [_vp, _i, _i, _vp, _i64, _vp, _i64, _vp, _vp, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
+    "wtp_comm_allreduce_stats": (_i, [_vp, C.POINTER(StepStats)]),
     "wtp_timers_get": (_i, [_vp, C.POINTER(_d)]),
     "wtp_timers_reset": (_i, [_vp]),
     "wtp_debug_diag": (_i, [_vp, C.POINTER(C.c_ulonglong)]),

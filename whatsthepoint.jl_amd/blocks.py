@@ -31,6 +31,7 @@ Global ids travel with the points, so a block run reproduces the single-domain r
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
@@ -107,6 +108,16 @@ class BlockShardedRelax:
         self.history = []
         self.last_local_points = int(owned_xyz.shape[0])
         self._next = None  # (planes, layers, strays) extracted together with the previous sweep
+        # Transport: torch.distributed by default.  WTP_COMM=abi moves the point-to-point rounds and the reduction of
+        # the statistics behind the C ABI (include/wtp.h: wtp_comm_* — the context owns an RCCL communicator), which
+        # is the path a caller without torch (the Julia side) uses; torch only carries the 128-byte
+        # communicator id to the other ranks here.
+        self.abi = os.environ.get("WTP_COMM", "") == "abi" and hasattr(engine, "ctx") and self.dev.type == "cuda"
+        self._rbuf = None
+        if self.abi:
+            box = [engine.ctx.comm_unique_id() if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            engine.ctx.comm_init(box[0], self.rank, self.world)
 
     # ---- geometry -----------------------------------------------------------------------------------------
     def _bounds(self, a: int):
@@ -143,6 +154,8 @@ class BlockShardedRelax:
         {x, y, z, gid_lo}, {gid_hi, 0, 0, 0}), the rest ghost rows {x, y, z, 0}.  Counts travel in one all-gather."""
         d, W = self.dist, self.world
         lo, hi = self._neighbour(a, -1), self._neighbour(a, +1)
+        if self.abi:
+            return self._round_abi(lo, hi, to_lo, split_lo, to_hi, split_hi)
         to_lo, to_hi = to_lo.to(self.cdev), to_hi.to(self.cdev)
         head = torch.tensor([float(split_lo), float(to_lo.shape[0]), float(split_hi), float(to_hi.shape[0])],
                             dtype=torch.float64, device=self.cdev)
@@ -168,6 +181,30 @@ class BlockShardedRelax:
                 req.wait()
         both = both.to(self.dev)
         return both[:n_lo], m_lo, both[n_lo:], m_hi
+
+    def _round_abi(self, lo, hi, to_lo, split_lo, to_hi, split_hi):
+        """The same round through wtp_comm_exchange_rows: one header row {migrant rows, 0, 0, 0} leads each payload
+        (the split the torch path sends with its count all-gather); the row counts travel inside the entry point."""
+        ctx = self.engine.ctx
+        head = lambda m: torch.tensor([[int(m), 0, 0, 0]], dtype=torch.int32, device=self.dev)
+        s_lo = torch.cat([head(split_lo), to_lo.to(self.dev)]).contiguous() if lo is not None else None
+        s_hi = torch.cat([head(split_hi), to_hi.to(self.dev)]).contiguous() if hi is not None else None
+        need = 65536 + int(0.35 * max(int(self.gid.shape[0]), 1))
+        if self._rbuf is None or self._rbuf[0].shape[0] < need:
+            self._rbuf = [torch.empty((need, 4), dtype=torch.int32, device=self.dev) for _ in range(2)]
+        r_lo, r_hi = self._rbuf
+        n_lo, n_hi = ctx.comm_exchange_rows(
+            -1 if lo is None else lo, -1 if hi is None else hi,
+            s_lo.data_ptr() if s_lo is not None else 0, 0 if s_lo is None else s_lo.shape[0],
+            s_hi.data_ptr() if s_hi is not None else 0, 0 if s_hi is None else s_hi.shape[0],
+            r_lo.data_ptr(), r_hi.data_ptr(), r_lo.shape[0])
+        out = []
+        for buf, n in ((r_lo, n_lo), (r_hi, n_hi)):
+            if n == 0:
+                out += [buf[:0], 0]
+            else:
+                out += [buf[1:n].clone(), int(buf[0, 0].item())]
+        return tuple(out)
 
     _rows4 = staticmethod(ShardedRelax._rows4)
     _pack_migrants = staticmethod(ShardedRelax._pack_migrants)
@@ -277,14 +314,21 @@ class BlockShardedRelax:
             self._next = (planes, nl, ns) if nl is not None else None
         else:
             st = eng.step()
-        mine = torch.tensor([st["max_force"], st["sum_u"], st["sum_u2"], float(st["n_move"]),
-                             float(st.get("n_uncovered", 0))], dtype=torch.float64, device=self.cdev)
-        allv = [torch.zeros_like(mine) for _ in range(self.world)]
-        self.dist.all_gather(allv, mine)
-        allv = torch.stack(allv).cpu()
-        out = dict(max_force=float(allv[:, 0].max()), sum_u=float(allv[:, 1].sum()), sum_u2=float(allv[:, 2].sum()),
-                   n_move=int(allv[:, 3].sum()), n_uncovered=int(allv[:, 4].sum()), n_ghost=n_ghost, n_owned=n_own,
-                   n_fallback=int(st.get("n_fallback", 0)))
+        if self.abi:
+            g = eng.ctx.comm_allreduce_stats({k: st[k] for k in ("max_force", "sum_u", "sum_u2", "n_move", "n_uncovered",
+                                                                  "argmin_r") if k in st})
+            out = dict(max_force=float(g["max_force"]), sum_u=float(g["sum_u"]), sum_u2=float(g["sum_u2"]),
+                       n_move=int(g["n_move"]), n_uncovered=int(g["n_uncovered"]), n_ghost=n_ghost, n_owned=n_own,
+                       n_fallback=int(st.get("n_fallback", 0)))
+        else:
+            mine = torch.tensor([st["max_force"], st["sum_u"], st["sum_u2"], float(st["n_move"]),
+                                 float(st.get("n_uncovered", 0))], dtype=torch.float64, device=self.cdev)
+            allv = [torch.zeros_like(mine) for _ in range(self.world)]
+            self.dist.all_gather(allv, mine)
+            allv = torch.stack(allv).cpu()
+            out = dict(max_force=float(allv[:, 0].max()), sum_u=float(allv[:, 1].sum()), sum_u2=float(allv[:, 2].sum()),
+                       n_move=int(allv[:, 3].sum()), n_uncovered=int(allv[:, 4].sum()), n_ghost=n_ghost, n_owned=n_own,
+                       n_fallback=int(st.get("n_fallback", 0)))
         if out["n_uncovered"] > 0:
             if attempt >= 4 or not hasattr(eng, "revert"):
                 raise RuntimeError(f"{out['n_uncovered']} queries reach past the ghost layer (w={self.w:g})")

@@ -57,7 +57,7 @@ int launch_occupancy_of(wtp_ctx* ctx, const void* fn, int threads, size_t smem) 
     return occ;
 }
 
-static int ensure_pinned(wtp_ctx* ctx, size_t bytes) {
+int ensure_pinned(wtp_ctx* ctx, size_t bytes) {
     if (ctx->host_pinned_cap >= bytes) return WTP_OK;
     if (ctx->host_pinned) hipHostFree(ctx->host_pinned);
     ctx->host_pinned = nullptr;
@@ -506,6 +506,7 @@ WTP_API int wtp_destroy(wtp_ctx* ctx) {
     if (!ctx) return WTP_OK;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    wtp_comm_finalize(ctx);
     DevBuf* bufs[] = {&ctx->pts[0], &ctx->pts[1], &ctx->pts[2], &ctx->raw_in, &ctx->cell_of, &ctx->rank_of,
                       &ctx->cell_cnt, &ctx->cell_start, &ctx->scan_tmp, &ctx->grid, &ctx->bbox_part,
                       &ctx->idx_out, &ctx->dist_out, &ctx->counts_out, &ctx->forces, &ctx->nn_dist,
@@ -513,7 +514,7 @@ WTP_API int wtp_destroy(wtp_ctx* ctx) {
                       &ctx->fb_count, &ctx->fb2_list, &ctx->fb2_count, &ctx->nn_list, &ctx->scratch, &ctx->diag,
                       &ctx->ins_in, &ctx->ins_elems, &ctx->ins_partial, &ctx->ins_out, &ctx->mesh_nodes, &ctx->mesh_pn, &ctx->mesh_io,
                       &ctx->wall_flags, &ctx->wall_tri, &ctx->wall_hint, &ctx->mesh_cls, &ctx->kd_nodes, &ctx->sp_hint, &ctx->occ, &ctx->box_dev,
-                      &ctx->cand_idx, &ctx->cand_dist, &ctx->f32_pts};
+                      &ctx->cand_idx, &ctx->cand_dist, &ctx->f32_pts, &ctx->comm_scratch};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     if (ctx->host_pinned) hipHostFree(ctx->host_pinned);

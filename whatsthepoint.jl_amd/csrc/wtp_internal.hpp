@@ -264,6 +264,9 @@ struct wtp_ctx {
     int64_t kd_m = 0;          // nodes in it; the key below identifies the boundary it was built from
     uint64_t kd_key = 0;
     int kd_dim = 0, kd_dtype = -1;
+    void* comm = nullptr;      // ncclComm_t (wtp_comm.hip); rank and size of the communicator
+    int comm_rank = 0, comm_size = 0;
+    wtp::DevBuf comm_scratch;
     void* host_pinned = nullptr;
     size_t host_pinned_cap = 0;
     // radius two-phase state
@@ -290,6 +293,7 @@ namespace wtp {
 
 // error plumbing
 int fail(wtp_ctx* ctx, int code, const std::string& msg);
+int ensure_pinned(wtp_ctx* ctx, size_t bytes); // the context's page-locked staging block, at least this large
 #define WTP_HIP(ctx, call)                                                                    \
     do {                                                                                      \
         hipError_t e_ = (call);                                                               \

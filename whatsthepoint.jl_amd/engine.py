@@ -246,6 +246,38 @@ class Context:
         L.check(self._h, self._lib.wtp_set_stream(self._h, C.c_void_p(int(stream_handle or 0)), int(ext)))
 
     # ---- measurement ---------------------------------------------------------------------------
+    # ---- the context's RCCL communicator (include/wtp.h: wtp_comm_*; one process per GPU) ----------------
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        L.check(self._h, self._lib.wtp_comm_unique_id(self._h, buf))
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, nranks: int):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        L.check(self._h, self._lib.wtp_comm_init(self._h, buf, int(rank), int(nranks)))
+
+    def comm_finalize(self):
+        L.check(self._h, self._lib.wtp_comm_finalize(self._h))
+
+    def comm_exchange_rows(self, peer_lo: int, peer_hi: int, send_lo_ptr: int, n_send_lo: int, send_hi_ptr: int,
+                           n_send_hi: int, recv_lo_ptr: int, recv_hi_ptr: int, cap: int):
+        """One round with the two neighbours along an axis (peer -1: none); device pointers to 16-byte rows.
+        Returns the received row counts (lo, hi); the rows are ordered on the context's stream."""
+        n_lo, n_hi = C.c_int64(0), C.c_int64(0)
+        L.check(self._h, self._lib.wtp_comm_exchange_rows(
+            self._h, int(peer_lo), int(peer_hi), C.c_void_p(send_lo_ptr or None), int(n_send_lo),
+            C.c_void_p(send_hi_ptr or None), int(n_send_hi), C.c_void_p(recv_lo_ptr or None), C.c_void_p(recv_hi_ptr or None),
+            int(cap), C.byref(n_lo), C.byref(n_hi)))
+        return int(n_lo.value), int(n_hi.value)
+
+    def comm_allreduce_stats(self, st: dict) -> dict:
+        s = L.StepStats()
+        for k, v in st.items():
+            if hasattr(s, k):
+                setattr(s, k, v)
+        L.check(self._h, self._lib.wtp_comm_allreduce_stats(self._h, C.byref(s)))
+        return {name: getattr(s, name) for name, _ in L.StepStats._fields_}
+
     def timers(self):
         out = (C.c_double * 4)()
         L.check(self._h, self._lib.wtp_timers_get(self._h, out))
