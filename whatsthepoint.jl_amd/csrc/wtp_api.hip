@@ -328,6 +328,13 @@ static int knn_dev_t(wtp_ctx* ctx, const T* d_xyz, int64_t n, int dim, int k, in
     sp = span_begin(ctx, 1);
     rc = launch_topology<T>(ctx, a);
     span_end(ctx, sp);
+    if (!rc && getenv("WTP_DEBUG")) { // hand-backs of the brick kernel to the exact path
+        int32_t h[2] = {0, 0};
+        hipMemcpyAsync(&h[0], a.fb_count, 4, hipMemcpyDeviceToHost, ctx->stream);
+        hipMemcpyAsync(&h[1], a.fb2_count, 4, hipMemcpyDeviceToHost, ctx->stream);
+        hipStreamSynchronize(ctx->stream);
+        fprintf(stderr, "[wtp] knn n=%lld k=%d: %d queries to the wave kernel, %d to the serial one\n", (long long)n, k, h[0], h[1]);
+    }
     ctx->n_sweep_launches += 1;
     ctx->relax.have_tree = false; // pts[] reused
     ctx->rad_valid = false;

@@ -423,7 +423,23 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
             const int cx = cell_coord(g, qp.x, 0), cy = cell_coord(g, qp.y, 1), cz = cell_coord(g, qp.z, 2);
             const int hx = cx - ox, hy = cy - oy, hz = cz - oz;
             const float g2 = safe_radius2(g, qp.x, qp.y, qp.z, cx, cy, cz, 1);
-            float tau = g2 < cap2 ? g2 : cap2;
+            // First filter radius of the k-selection: the ball that is EXPECTED to hold a.cap_count points at the density
+            // this query sees — its 27 cells hold n27, so r^3 = cap_count / n27 * 27 / (4 pi / 3) cell volumes.  A fixed
+            // gamma_cap * c served the interior and failed at the faces of the cloud, where half the block is empty and
+            // the k-th neighbour lies 1.26 x further: 12 % of a 1 M-point cloud sits in face cells, a tenth of those
+            // came up short and went to the exact path (1.24 % of all queries, 0.14 of the call's 0.74 ms).
+            float capq = cap2;
+            if (!CS && MODE != 2 && a.cap_count > 0.f) {
+                int n27 = 0;
+#pragma unroll
+                for (int r9 = 0; r9 < 9; ++r9) {
+                    const int b = ((hz + r9 / 3 - 1) * HY + (hy + r9 % 3 - 1)) * HX + (hx - 1);
+                    n27 += sm->hstart[b + 3] - sm->hstart[b];
+                }
+                const float x = a.cap_count * 6.4458f / (float)(n27 > 1 ? n27 : 1);
+                capq = (g.c * g.c) * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * 0.66666667f);
+            }
+            float tau = g2 < capq ? g2 : capq;
             // MODE 2 (RadiusTopology): the threshold IS the answer — everything with d2 <= r^2 (inclusive,
             // src/topology.jl:93); the 27 cells are complete when r lies inside the provable radius
             bool rad_fail = false;
@@ -915,6 +931,7 @@ int launch_brick_radius(wtp_ctx* ctx, SearchArgs<float>& a) {
 template <> int launch_topology<float>(wtp_ctx* ctx, SearchArgs<float>& a) {
     if (a.k > kFastKMax - 1 || ctx->force_generic) return launch_generic_topology<float>(ctx, a, true);
     a.gamma_cap = (float)ctx->gamma_cap;
+    a.cap_count = (float)(4.18879 * ctx->gamma_cap * ctx->gamma_cap * ctx->gamma_cap * ctx->rho * (a.k + 1) / 22.0);
     WTP_HIP(ctx, hipMemsetAsync(a.fb_count, 0, sizeof(int32_t), ctx->stream));
     int rc = a.k == 21 ? brick_launch<0, 21, 0>(ctx, a) : brick_launch<0, 0, 0>(ctx, a);
     if (rc) return rc;
@@ -936,6 +953,7 @@ template <> int launch_sweep<float>(wtp_ctx* ctx, SearchArgs<float>& a, bool fre
         return rc;
     }
     a.gamma_cap = (float)ctx->gamma_cap_sweep;
+    a.cap_count = (float)(4.18879 * ctx->gamma_cap_sweep * ctx->gamma_cap_sweep * ctx->gamma_cap_sweep * ctx->rho * (a.k + 1) / 22.0);
     const int sp = span_begin(ctx, 1);
     // ClippedSpacingForce (the reference default) takes the compact-support sweep unless
     // WTP_FULL_SELECT=1 asks for the explicit k-selection on every query (both give the same output)

@@ -136,6 +136,7 @@ template <typename T> struct SearchArgs {
     int32_t* uncovered;
     // tunables
     T gamma_cap;               // initial filter radius cap, in cell edges
+    float cap_count;           // k-selection kernels: points the first filter ball is expected to hold (0: fixed gamma_cap * c)
     T tnn_frac;                // CS sweeps: nearest-neighbour margin of the ring, in cell edges (WTP_TNN, default 0.8)
     int32_t brick_hcap;        // LDS point capacity for the brick kernel (0 = default)
     int32_t cs2_bx;            // > 0: brick length (own cells along x) of the round-2 compact-support sweep (wtp_cs2.hip)
