@@ -23,6 +23,13 @@ law = w.BoundaryLayerSpacing(b, at_wall=hw, bulk=4 * hw, layer_thickness=0.2)
 snap = np.concatenate([b, x])
 with ctx.relax(snap, len(b), law.desc(), force, 21, hw / 2000, hw / 20) as t:
     t.step(True); t.run_async_free(3, 1)
-    t0 = time.perf_counter()
-    conv, st = t.run(20, 1)
-    print("ms/iter", (time.perf_counter() - t0) / 20 * 1e3, "n_fallback", st["n_fallback"])
+    for stage in range(int(os.environ.get("STAGES", "1"))):   # later stages: the cloud has relaxed, points move less per sweep
+        t0 = time.perf_counter()
+        conv, st = t.run(20, 1)
+        print("iterations", 4 + 120 * stage, "ms/iter", (time.perf_counter() - t0) / 20 * 1e3, "n_fallback", st["n_fallback"],
+              "max_force", conv[-1], flush=True)
+        if os.environ.get("WTP_DEBUG_KD"):
+            import ctypes as C
+            out = (C.c_ulonglong * 16)()
+            w.load_library().wtp_debug_diag(ctx._h, out)
+        t.run_async_free(100, 1)

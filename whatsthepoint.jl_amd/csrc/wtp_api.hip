@@ -521,7 +521,7 @@ WTP_API int wtp_destroy(wtp_ctx* ctx) {
                       &ctx->fb_count, &ctx->fb2_list, &ctx->fb2_count, &ctx->nn_list, &ctx->scratch, &ctx->diag,
                       &ctx->ins_in, &ctx->ins_elems, &ctx->ins_partial, &ctx->ins_out, &ctx->mesh_nodes, &ctx->mesh_pn, &ctx->mesh_io,
                       &ctx->wall_flags, &ctx->wall_tri, &ctx->wall_hint, &ctx->mesh_cls, &ctx->kd_nodes, &ctx->sp_hint, &ctx->occ, &ctx->box_dev,
-                      &ctx->cand_idx, &ctx->cand_dist, &ctx->f32_pts, &ctx->comm_scratch};
+                      &ctx->cand_idx, &ctx->cand_dist, &ctx->f32_pts, &ctx->comm_scratch, &ctx->sp_cert};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     if (ctx->host_pinned) hipHostFree(ctx->host_pinned);
@@ -926,14 +926,18 @@ static int relax_init_impl(wtp_ctx* ctx, const void* snap_xyz, bool on_device, i
         if ((rc = ensure(ctx, ctx->spacing_pp, ts * (size_t)n))) return rc;
         if ((rc = ensure(ctx, ctx->sp_hint, sizeof(int32_t) * (size_t)n))) return rc;
         WTP_HIP(ctx, hipMemsetAsync(ctx->sp_hint.p, 0xFF, sizeof(int32_t) * (size_t)n, ctx->stream)); // -1: no hint
+        if ((rc = ensure(ctx, ctx->sp_cert, 4 * ts * (size_t)n))) return rc;
+        WTP_HIP(ctx, hipMemsetAsync(ctx->sp_cert.p, 0xFF, 4 * ts * (size_t)n, ctx->stream)); // no certificate yet
         if (dtype == WTP_F32)
             rc = launch_spacing_session<float>(ctx, (const float4*)ctx->pts[0].p, n, 0, ctx->kd_nodes.p, ctx->kd_m,
                                                spacing->kind, spacing->p0, spacing->p1, spacing->p2,
-                                               (float*)ctx->spacing_pp.p, (int32_t*)ctx->sp_hint.p);
+                                               (float*)ctx->spacing_pp.p, (int32_t*)ctx->sp_hint.p, nullptr, nullptr,
+                                               ctx->sp_cert.p);
         else
             rc = launch_spacing_session<double>(ctx, (const double4*)ctx->pts[0].p, n, 0, ctx->kd_nodes.p, ctx->kd_m,
                                                 spacing->kind, spacing->p0, spacing->p1, spacing->p2,
-                                                (double*)ctx->spacing_pp.p, (int32_t*)ctx->sp_hint.p);
+                                                (double*)ctx->spacing_pp.p, (int32_t*)ctx->sp_hint.p, nullptr, nullptr,
+                                                ctx->sp_cert.p);
         if (rc) return rc;
     }
     if ((rc = sync(ctx))) return rc;
@@ -1160,7 +1164,7 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
         rc = launch_spacing_session<T>(ctx, (const Pt<T>*)ctx->pts[r.bufP].p, r.n, r.n_fixed, ctx->kd_nodes.p, ctx->kd_m,
                                        r.spacing_kind, r.sp_p0, r.sp_p1, r.sp_p2, (T*)ctx->spacing_pp.p,
                                        (int32_t*)ctx->sp_hint.p, r.have_tree ? (const int32_t*)ctx->cell_start.p : nullptr,
-                                       ctx->grid.p);
+                                       ctx->grid.p, getenv("WTP_SP_CERT_OFF") ? nullptr : ctx->sp_cert.p);
         span_end(ctx, sps);
         if (rc) return rc;
     }
@@ -1224,23 +1228,7 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
     if (!ctx->counters_clean) WTP_HIP(ctx, hipMemsetAsync(ctx->fb_count.p, 0, 64, ctx->stream));
     ctx->counters_clean = false; // (set again by the step's final reduction, which zeroes the block after reading it)
     a.used_brick = a.used_wave = a.used_generic = 0;
-    // without the wall rule nothing follows the sweep's last kernel: its last block does the final reduction
-    const bool fused_reduce = !r.wall_active;
-    if (fused_reduce) {
-        a.reduce_out = d_slot;
-        a.reduce_wave_base = brick_partials();
-        a.reduce_counters = (int32_t*)ctx->fb_count.p;
-    }
     if ((rc = launch_sweep<T>(ctx, a, fresh))) return rc;
-    if (fused_reduce) {
-        ctx->counters_clean = true;
-        r.bufOld = r.bufP; // p_old (src/repel.jl:244)
-        r.bufP = o;
-        r.can_revert = true;
-        r.have_point_data = true;
-        r.sweeps_since_rebuild += 1;
-        return WTP_OK;
-    }
     int sp = span_begin(ctx, 2);
     if (r.wall_active) { // p[id] = constrain(id, x_i, x_i + disp) (src/repel.jl:290): the octree wall rule
         char* wf = (char*)ctx->wall_flags.p;
@@ -2033,7 +2021,13 @@ WTP_API int wtp_debug_diag(wtp_ctx* ctx, unsigned long long out[16]) {
     if ((rc = ensure(ctx, ctx->diag, 128))) return rc;
     WTP_HIP(ctx, hipMemcpyAsync(out, ctx->diag.p, 128, hipMemcpyDeviceToHost, ctx->stream));
     WTP_HIP(ctx, hipMemsetAsync(ctx->diag.p, 0, 128, ctx->stream));
-    return sync(ctx);
+    if ((rc = sync(ctx))) return rc;
+    if (getenv("WTP_DEBUG_KD")) { // diagnostic builds: node visits of the spacing law's tree walk
+        unsigned long long kd[2] = {0, 0};
+        wtp::debug_kd_steps(kd);
+        fprintf(stderr, "[wtp] kd walk: %llu node visits by %llu wave-walks (%.1f per walk)\n", kd[0], kd[1], kd[1] ? (double)kd[0] / (double)kd[1] : 0.0);
+    }
+    return WTP_OK;
 }
 
 // ---- device-side helpers for bench.py / the sharded driver (not part of the drop-in surface) -----

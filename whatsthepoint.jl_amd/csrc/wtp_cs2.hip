@@ -810,7 +810,7 @@ __global__ __launch_bounds__(kNnFixThreads, 8) void cs2_nnfix_kernel(SearchArgs<
 constexpr int kBallThreads = 256;
 constexpr int kBallBlocksMax = 512;
 constexpr int kBallRMax = 4;
-__global__ __launch_bounds__(kBallThreads) void cs_ball_kernel(SearchArgs<float> a, const int32_t* __restrict__ list,
+__global__ __launch_bounds__(kBallThreads, 6) void cs_ball_kernel(SearchArgs<float> a, const int32_t* __restrict__ list,
                                                                const int32_t* __restrict__ list_count,
                                                                int32_t* __restrict__ out_list, int32_t* __restrict__ out_count,
                                                                int part_base) {

@@ -108,21 +108,6 @@ __global__ __launch_bounds__(kThreads) void generic_kernel(SearchArgs<T> a, cons
     if (MODE == 1) {
         acc_block_reduce(acc, sm_acc);
         if (threadIdx.x == 0) acc_store(&a.partials[part_base + blockIdx.x], acc);
-        // This is the last launch of a sweep: the block that finishes last reduces the step's partials (every
-        // earlier kernel of the step has completed in stream order; this kernel's own slots are published by the
-        // fence before the ticket).  No block waits for another.
-        if (a.reduce_out) {
-            __shared__ int last_block;
-            __threadfence();
-            __syncthreads();
-            if (threadIdx.x == 0) last_block = atomicAdd(&a.reduce_counters[14], 1) == (int)gridDim.x - 1;
-            __syncthreads();
-            if (last_block) {
-                __threadfence();
-                reduce_partials_block(a.partials, a.n_partials, a.used_brick, a.reduce_wave_base, a.used_wave, a.used_generic,
-                                      a.fb_count, a.uncovered, (const int32_t*)nullptr, a.reduce_out, a.reduce_counters, sm_acc);
-            }
-        }
     }
 }
 

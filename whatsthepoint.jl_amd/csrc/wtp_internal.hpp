@@ -108,11 +108,6 @@ template <typename T> struct SearchArgs {
     // blocks each sweep kernel was launched with = partial slots it wrote (set by the launchers):
     // brick [0, used_brick), wave [brick_partials(), +used_wave), serial [n_partials - kGenericPartials, +used_generic)
     int32_t used_brick, used_wave, used_generic;
-    // the step's final reduction rides in the last block of the serial kernel (one launch less) when the caller
-    // sets these: stats slot, wave partial base, counter block (ticket in [14]; zeroed after use), escaped counter
-    wtp_step_stats* reduce_out;
-    int32_t reduce_wave_base;
-    int32_t* reduce_counters;
     // RadiusTopology through the brick kernel: r^2, row lengths out (count phase) or row starts in (fill phase)
     T radius2;
     int32_t* rad_counts;
@@ -268,6 +263,7 @@ struct wtp_ctx {
     void* comm = nullptr;      // ncclComm_t (wtp_comm.hip); rank and size of the communicator
     int comm_rank = 0, comm_size = 0;
     wtp::DevBuf comm_scratch;
+    wtp::DevBuf sp_cert;       // device-evaluated spacing laws: per point, where it stood at its last tree walk and the bound that walk left (wtp_spacing.hip)
     void* host_pinned = nullptr;
     size_t host_pinned_cap = 0;
     // radius two-phase state
@@ -351,6 +347,7 @@ int launch_brick_radius(wtp_ctx* ctx, SearchArgs<float>& a);
 // round-2 compact-support sweep (wtp_cs2.hip)
 int launch_cs2(wtp_ctx* ctx, SearchArgs<float>& a);
 int launch_cs2_followup(wtp_ctx* ctx, SearchArgs<float>& a);
+int debug_kd_steps(unsigned long long out[2]); // -DWTP_DIAG builds: node visits / wave-walks of the spacing law's tree walk since the last call
 int launch_cs_ball(wtp_ctx* ctx, SearchArgs<float>& a, int32_t* rest_list, int32_t* rest_count);
 int launch_cs2_census(wtp_ctx* ctx, int BX, unsigned int* d_out513);
 int cs2_max_bx();
@@ -393,7 +390,7 @@ int launch_spacing_eval(wtp_ctx* ctx, const T* d_xyz, int64_t n, int dim, const 
 template <typename T>
 int launch_spacing_session(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int64_t first_id, const void* d_nodes, int64_t m,
                            int kind, double p0, double p1, double p2, T* d_spacing_pp, int32_t* d_hint,
-                           const int32_t* d_cell_start = nullptr, const void* d_grid = nullptr);
+                           const int32_t* d_cell_start = nullptr, const void* d_grid = nullptr, void* d_cert = nullptr);
 // fp64 topology through an fp32 candidate search (wtp_hash.hip)
 int launch_origin(wtp_ctx* ctx, const double4* pts, int64_t n, double* d_org4);
 int launch_to_local_f32(wtp_ctx* ctx, const double4* in, int64_t n, const double* d_org4, float4* out);

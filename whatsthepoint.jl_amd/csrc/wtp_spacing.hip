@@ -30,6 +30,13 @@ namespace wtp {
 
 static constexpr int kSpThreads = 256;
 
+#ifndef WTP_DIAG
+#define WTP_DIAG 0
+#endif
+#if WTP_DIAG
+__device__ unsigned long long g_kd_steps[2]; // diagnostic builds: node visits of all waves, waves (wtp_debug_kd_steps)
+#endif
+
 // nodes in the left subtree of a left-balanced binary tree with n nodes
 static int64_t kd_left_size(int64_t n) {
     if (n <= 1) return 0;
@@ -128,9 +135,14 @@ __device__ inline T box_d2(const KdBox<T>& b, T qx, T qy, T qz) {
 // walks per wave) 3.3 ms, packet traversal 1.0 ms.
 template <typename T>
 __device__ inline T kd_nearest_d2(const KdNode<T>* __restrict__ nodes, int32_t m, T qx, T qy, T qz, bool active,
-                                  int32_t hint, int32_t* best_node, int32_t* __restrict__ stack /* LDS, this wave's */) {
+                                  int32_t hint, int32_t* best_node, int32_t* __restrict__ stack /* LDS, this wave's */,
+                                  T* other_lb = nullptr) {
     T best = active ? Lim<T>::inf() : (T)-1; // box_d2 >= 0 > -1: an inactive lane never asks for anything
     int32_t bn = -1;
+    // *other_lb: a lower bound on the canonical d2 of every boundary point OTHER than the winner — the smaller of the
+    // second-best point this lane evaluated and the boxes of the subtrees the wave skipped (each lane's own distance to
+    // them).  The caller turns it into a certificate that the winner is still the nearest after the query has moved.
+    T lb = Lim<T>::inf();
     if (active && hint >= 0 && hint < m) {
         const Pt<T> p = nodes[hint].p;
         best = dist2<T>(qx, qy, qz, p.x, p.y, p.z);
@@ -138,15 +150,28 @@ __device__ inline T kd_nearest_d2(const KdNode<T>* __restrict__ nodes, int32_t m
     }
     int sp = 0;        // uniform
     int32_t node = 0;  // uniform
+#if WTP_DIAG
+    int kd_steps_ = 0;
+#endif
     for (;;) {
+#if WTP_DIAG
+        ++kd_steps_;
+#endif
         node = __builtin_amdgcn_readfirstlane(node);
         const KdNode<T> nd = nodes[node]; // one uniform fetch per step
-        const bool want = box_d2<T>(nd.box, qx, qy, qz) < best;
+        const T bd2 = box_d2<T>(nd.box, qx, qy, qz);
+        const bool want = bd2 < best;
         bool descended = false;
-        if (__any(want)) {
+        if (!__any(want)) {
+            lb = bd2 < lb ? bd2 : lb; // the whole subtree is skipped: nothing in it is nearer than its box
+        } else {
             const Pt<T> p = nd.p;
             const T d2 = dist2<T>(qx, qy, qz, p.x, p.y, p.z);
             const bool better = active && d2 < best;
+            if (node != bn) { // (the hint's own node comes up again in the walk)
+                const T loser = better ? best : d2;
+                lb = loser < lb ? loser : lb;
+            }
             bn = better ? node : bn;
             best = better ? d2 : best;
             const int32_t sd = w_to_id(p.w);
@@ -169,7 +194,14 @@ __device__ inline T kd_nearest_d2(const KdNode<T>* __restrict__ nodes, int32_t m
             node = stack[--sp];
         }
     }
+#if WTP_DIAG
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&g_kd_steps[0], (unsigned long long)kd_steps_);
+        atomicAdd(&g_kd_steps[1], 1ull);
+    }
+#endif
     *best_node = bn;
+    if (other_lb) *other_lb = lb;
     return best;
 }
 
@@ -222,20 +254,52 @@ __global__ void spacing_session_kernel(const Pt<T>* __restrict__ pts, int64_t n,
                                        const KdNode<T>* __restrict__ nodes, int32_t m, SpacingLaw<T> law,
                                        T* __restrict__ spacing_pp, int32_t* __restrict__ hint,
                                        const int32_t* __restrict__ stop, const int32_t* __restrict__ cell_start,
-                                       const Grid<T>* __restrict__ gp) {
+                                       const Grid<T>* __restrict__ gp, Pt<T>* __restrict__ cert) {
     __shared__ int32_t kd_stack[kSpThreads / 64][64];
     if (stop && *stop) return;
+    // Most walks can be skipped.  A walk leaves, per point, where it stood (x_ref) and a lower bound lb on the distance
+    // to every boundary point other than the winner b.  After the point has moved to x, any other boundary point q has
+    // |x - q| >= |x_ref - q| - |x - x_ref| >= sqrt(lb) - |x - x_ref|; if that still exceeds |x - b|, b is the nearest
+    // point of x as well and the minimum is |x - b|^2 — the very expression the walk would return, bit for bit.  Points
+    // move a fraction of a spacing per sweep and ever less as the cloud relaxes; only the lanes whose certificate
+    // fails walk (a wave of fewer interested lanes visits fewer nodes).
+    const T eps = sizeof(T) == 4 ? (T)1e-6 : (T)1e-14;
     auto one = [&](int64_t slot, bool on) {
         const Pt<T> p = pts[on ? slot : 0];
         const int32_t id = w_to_id(p.w);
         const bool active = on && id >= first_id;
-        if (!__any(active)) return;
-        int32_t bn;
-        const T d2 = kd_nearest_d2<T>(nodes, m, p.x, p.y, p.z, active, active ? hint[id] : -1, &bn,
-                                      kd_stack[threadIdx.x >> 6]);
+        bool need = active;
+        int32_t h = -1;
         if (active) {
+            h = hint[id];
+            if (cert && h >= 0 && h < m) {
+                const Pt<T> c = cert[id];
+                if (c.w > (T)0) { // (never walked: the bits of -1)
+                    const Pt<T> b = nodes[h].p;
+                    const T d2b = dist2<T>(p.x, p.y, p.z, b.x, b.y, b.z);
+                    const T moved = wsqrt(dist2<T>(p.x, p.y, p.z, c.x, c.y, c.z));
+                    if ((wsqrt(d2b) + moved) * ((T)1 + eps) < wsqrt(c.w) * ((T)1 - eps)) {
+                        need = false;
+                        spacing_pp[id] = spacing_law<T>(law, wsqrt(d2b));
+                    }
+                }
+            }
+        }
+        if (!__any(need)) return;
+        int32_t bn;
+        T lb;
+        const T d2 = kd_nearest_d2<T>(nodes, m, p.x, p.y, p.z, need, need ? h : -1, &bn, kd_stack[threadIdx.x >> 6], &lb);
+        if (need) {
             spacing_pp[id] = spacing_law<T>(law, wsqrt(d2));
             hint[id] = bn; // points move a fraction of a spacing per sweep: next time this is (nearly) the answer
+            if (cert) {
+                Pt<T> c;
+                c.x = p.x;
+                c.y = p.y;
+                c.z = p.z;
+                c.w = lb;
+                cert[id] = c;
+            }
         }
     };
     if (!cell_start) { // no grid yet (session setup): slot order
@@ -312,13 +376,24 @@ int launch_spacing_eval(wtp_ctx* ctx, const T* d_xyz, int64_t n, int dim, const 
 template <typename T>
 int launch_spacing_session(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int64_t first_id, const void* d_nodes, int64_t m,
                            int kind, double p0, double p1, double p2, T* d_spacing_pp, int32_t* d_hint,
-                           const int32_t* d_cell_start, const void* d_grid) {
+                           const int32_t* d_cell_start, const void* d_grid, void* d_cert) {
     SpacingLaw<T> law{kind, (T)p0, (T)p1, (T)p2};
     hipLaunchKernelGGL(spacing_session_kernel<T>, dim3(sp_grid(n)), dim3(kSpThreads), 0, ctx->stream, pts, n,
                        (int32_t)first_id, (const KdNode<T>*)d_nodes, (int32_t)m, law, d_spacing_pp, d_hint, ctx->stop_dev,
-                       d_cell_start, (const Grid<T>*)d_grid);
+                       d_cell_start, (const Grid<T>*)d_grid, (Pt<T>*)d_cert);
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;
+}
+
+int debug_kd_steps(unsigned long long out[2]) {
+#if WTP_DIAG
+    unsigned long long z[2] = {0, 0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kd_steps), sizeof(z)) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_kd_steps), z, sizeof(z)) != hipSuccess;
+#else
+    out[0] = out[1] = 0;
+    return 0;
+#endif
 }
 
 #define INST(T)                                                                                              \
@@ -327,7 +402,7 @@ int launch_spacing_session(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int64_t fi
     template int launch_spacing_eval<T>(wtp_ctx*, const T*, int64_t, int, const void*, int64_t, int, double, \
                                         double, double, T*);                                                 \
     template int launch_spacing_session<T>(wtp_ctx*, const Pt<T>*, int64_t, int64_t, const void*, int64_t, int, \
-                                           double, double, double, T*, int32_t*, const int32_t*, const void*);
+                                           double, double, double, T*, int32_t*, const int32_t*, const void*, void*);
 INST(float)
 INST(double)
 #undef INST
