@@ -80,3 +80,26 @@ def test_repel_with_boundary_layer_law_runs_on_device(O, wtp, ctx):
     new = wtp.repel(cloud, law, max_iters=5, stall_after=0, tol=0.0, convergence=conv, trace=trace, ctx=ctx)
     assert len(conv) == 5 and len(trace) == 5 and len(new.volume.points()) == 5000
     assert all(t["s"] > 0.03 - 1e-6 and t["s"] < 0.07 + 1e-6 for t in trace)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_law_values_stay_exact_when_points_barely_move_and_when_one_is_moved_by_hand(O, wtp, ctx, dtype):
+    """The session skips the boundary-tree walk for a point whose previous walk still certifies its winner
+    (wtp_spacing.hip); the value must be the brute-force one every sweep, also for a point thrown across the box."""
+    n_fixed, n_move, k = 1200, 5000, 21
+    b = _boundary(wtp, dtype, n_fixed)
+    v = (wtp.synth.uniform(n_move, 3, dtype, 11) * dtype(0.9) + dtype(0.05))
+    snap = np.concatenate([b, v])
+    law = wtp.LogLike(b, 0.07, 1.2)
+    force = dict(kind=2, beta=0.2, u0=1.0, gamma=3.0)
+    with ctx.relax(snap, n_fixed, law.desc(), force, k, 1e-7, 1e-5) as sess:      # tiny steps: certificates hold
+        cur = snap.copy()
+        for it in range(10):
+            if it == 6:                                                           # the kick of src/repel.jl:431
+                far = np.array([0.93, 0.08, 0.51], dtype=dtype)
+                sess.set_point(17, far)
+                cur[n_fixed + 17] = far
+            sess.step(it % 3 == 0)
+            want = O.spacing_loglike(cur, b, 0.07, 1.2)
+            assert np.array_equal(sess.spacings()[n_fixed:], want[n_fixed:]), it
+            cur[n_fixed:] = sess.positions()
