@@ -303,9 +303,9 @@ def self_launch(n: int) -> int:
 
 def ctx_rho() -> float:
     try:
-        return float(os.environ.get("WTP_RHO", "8"))
+        return float(os.environ.get("WTP_RHO", "9"))   # the library's default (csrc/wtp_internal.hpp)
     except ValueError:
-        return 8.0
+        return 9.0
 
 
 def main():

@@ -1164,7 +1164,7 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
         rc = launch_spacing_session<T>(ctx, (const Pt<T>*)ctx->pts[r.bufP].p, r.n, r.n_fixed, ctx->kd_nodes.p, ctx->kd_m,
                                        r.spacing_kind, r.sp_p0, r.sp_p1, r.sp_p2, (T*)ctx->spacing_pp.p,
                                        (int32_t*)ctx->sp_hint.p, r.have_tree ? (const int32_t*)ctx->cell_start.p : nullptr,
-                                       ctx->grid.p, getenv("WTP_SP_CERT_OFF") ? nullptr : ctx->sp_cert.p);
+                                       ctx->grid.p, getenv("WTP_SP_CERT_OFF") ? nullptr : ctx->sp_cert.p); // (the switch: A/B of the certificates)
         span_end(ctx, sps);
         if (rc) return rc;
     }
