@@ -180,6 +180,19 @@ def other_paths(ctx, torch, np, wtp_amd, extra_legs=False, e2e=True):
         "value": round(len(t) / dt / 1e6, 2), "unit": "Mpoints/s", "ms": round(dt * 1e3, 2), "kernel_ms": round(dev * 1e3, 2),
         "inside_fraction": round(float(ins2.mean()), 4), "agrees_with_greens": round(float((ins2 == ins).mean()), 5),
         "note": "wtp_mesh_query (bounding-volume tree, per-lane stackless walk), host arrays in and out, unsorted queries"}
+    # Float64 clouds (the reference's default element type): the compact-support sweep of csrc/wtp_brick64.hip,
+    # bit-identical to the sequential evaluation
+    n64 = 4_000_000
+    s64 = float(n64) ** (-1.0 / 3.0)
+    x64 = wtp_amd.synth.uniform(n64, 3, np.float64, 7)
+    with ctx.relax(x64, 0, s64, dict(kind=2, beta=0.2, u0=1.0, gamma=3.0), 21, s64 / 2000, s64 / 20) as t:
+        t.run_async_free(3, 1)
+        t0 = time.perf_counter()
+        t.run(10, 1)
+        dt = (time.perf_counter() - t0) / 10
+    out["repel_f64_4M"] = {"value": round(n64 / dt / 1e6, 1), "unit": "Mpoints/s", "ms_per_iter": round(dt * 1e3, 3),
+                           "note": "Float64 cloud, ClippedSpacingForce: brick_cs_kernel<double> (sums in ascending (d2, id) order)"}
+    del x64
     if not e2e:
         return out
     # The legs below launch the headline's own kernel on other workloads.  They are part of the default run
