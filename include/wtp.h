@@ -346,6 +346,92 @@ int wtp_comm_exchange_rows(wtp_ctx* ctx, int peer_lo, int peer_hi, const void* d
  * becomes the global minimum; argmin_i / argmin_j stay local indices on the rank that holds it and become -1 elsewhere. */
 int wtp_comm_allreduce_stats(wtp_ctx* ctx, wtp_step_stats* stats);
 
+/* ---- the whole sharded iteration behind the boundary ------------------------------------------------
+ * wtp_block_* run one rank's share of a multi-GPU repel: what `_relax!`'s loop body (src/repel.jl:243-334) becomes when
+ * the cloud is cut into the cells of an orthtree partition, one cell (an axis-aligned box) per rank.  The caller hands
+ * over its owned points and every rank's box once, then calls wtp_block_step once per iteration — ghost exchange,
+ * migration, hash, sweep, the global statistics and the ghost-width check all happen inside:
+ *
+ *   exchange   ONE grouped point-to-point round with every spatially adjacent rank (ncclSend/ncclRecv inside one
+ *              group: faces, edges and corners directly, 7 peers for 2 x 2 x 2 octants, one xGMI link each).  Row counts
+ *              are known beforehand: they rode with the previous iteration's statistics, so no host round trip sits
+ *              between the counts and the rows.
+ *   ghosts     rank q receives every foreign point within ghost_width + margin of its box; they become the fixed
+ *              head of the local snapshot (searched, never moved, never counted).
+ *   migration  a point that strayed more than `margin` past its owner's box travels in the same round, straight to
+ *              the rank whose box holds it (64-bit global ids travel along); the sender keeps it as a ghost for
+ *              this iteration.
+ *   sweep      hash + sweep of [ghosts ; owned] (wtp_relax_step's kernels), then, from the positions it produced, the
+ *              rows and counts of the NEXT exchange.
+ *   statistics one all-gather per iteration carries {the step's statistics, the next row counts}; every rank reduces
+ *              the gathered statistics in rank order (a fixed order: the global sums are reproducible).  This is the
+ *              iteration's only host synchronisation.
+ *   coverage   the sweep counts the queries whose support reaches past the box the snapshot is complete for; if any rank
+ *              reports one, all ranks undo the step, widen the ghost layer by 1.5x and repeat it.
+ * fp32, 3-D; constant spacing or a device-evaluated law (LOGLIKE / BOUNDARY_LAYER: ghosts need no spacing, only queries
+ * do).  Needs wtp_comm_init (the context's RCCL communicator) or a caller-supplied transport.  */
+typedef struct wtp_block_desc {
+    int32_t rank, nranks;
+    const double* boxes;  /* nranks x 6: {lo x, lo y, lo z, hi x, hi y, hi z} of every rank's box, half-open [lo, hi);
+                             the boxes tile space (outer ends +-inf); identical on every rank                       */
+    double ghost_width;   /* w: at least the largest support u0 * s of a query near a face (checked, widened on demand) */
+    double margin;        /* lazy migration: a point changes owner once it is this far outside its box; < 0: w / 4  */
+} wtp_block_desc;
+
+typedef struct wtp_block_info {
+    int64_t n_owned, n_ghost;   /* this rank, in the iteration just done                                         */
+    int64_t n_sent_rows, n_recv_rows; /* ghost rows of the iteration's exchange (16 bytes each)                  */
+    int64_t n_emigrated, n_immigrated;
+    int32_t n_peers;            /* ranks this rank exchanges with                                                 */
+    int32_t widened;            /* times the ghost layer was widened so far                                       */
+    int32_t host_syncs;         /* host synchronisations this call made (1 in steady state)                       */
+    int32_t redone;             /* 1 if the step was undone and repeated with a wider layer                       */
+    double ghost_width;         /* current w                                                                      */
+} wtp_block_info;
+
+/* Optional transport in place of the context's RCCL communicator (MPI without GPU awareness, tests with several ranks
+ * on one GPU): host buffers only; the library stages through the host around the callbacks.  All ranks call in step. */
+typedef struct wtp_transport {
+    void* user;
+    /* every rank contributes `bytes` bytes; recv holds nranks * bytes, rank-major */
+    int (*allgather)(void* user, const void* send, void* recv, int64_t bytes);
+    /* message j goes to and comes from rank peers[j] (send_bytes[j] / recv_bytes[j] may be 0) */
+    int (*exchange)(void* user, int n_msgs, const int* peers, const void* const* send, const int64_t* send_bytes,
+                    void* const* recv, const int64_t* recv_bytes);
+} wtp_transport;
+int wtp_block_set_transport(wtp_ctx* ctx, const wtp_transport* t); /* NULL: back to RCCL */
+
+/* d_owned_xyz: n_owned x 3 fp32 on the context's GPU; d_gid: n_owned int64 global ids (device).  spacing / force / k /
+ * alpha as wtp_relax_init.  Collective: every rank calls it.  */
+int wtp_block_open(wtp_ctx* ctx, const wtp_block_desc* desc, const void* d_owned_xyz, const int64_t* d_gid,
+                   int64_t n_owned, const wtp_spacing_desc* spacing, const wtp_force_desc* force, int k,
+                   double alpha_lo, double alpha_max);
+/* One iteration; stats = the GLOBAL view (max / sums over all ranks; argmin_i / argmin_j are global ids, on every rank);
+ * info may be NULL.  */
+int wtp_block_step(wtp_ctx* ctx, wtp_step_stats* stats, wtp_block_info* info);
+/* n_iters iterations; conv_out[n_iters] = global max |F| s per iteration (may be NULL).  */
+int wtp_block_run(wtp_ctx* ctx, int n_iters, double* conv_out, wtp_step_stats* last, wtp_block_info* info);
+/* The reference's stop rules on the global statistics (src/repel.jl:305-334, same order as wtp_relax_run_until): every
+ * rank sees the same numbers, so all stop at the same iteration.  */
+int wtp_block_run_until(wtp_ctx* ctx, int max_iters, double tol, int stall_after, double cv_target, double* conv_out,
+                        int* n_done, int* reason, wtp_step_stats* last);
+/* Owned points now: *n_owned of them; d_xyz_out (n x 3 fp32) and d_gid_out (int64) are device buffers of at least
+ * `cap` entries, either may be NULL (then only the count is returned).  */
+int wtp_block_get(wtp_ctx* ctx, void* d_xyz_out, int64_t* d_gid_out, int64_t cap, int64_t* n_owned);
+int wtp_block_close(wtp_ctx* ctx);
+/* Host-only helpers (no GPU): the block grid px x py x pz for nranks (as cubic as possible, larger factors on later
+ * axes) and the Morton rank of block (ix, iy, iz) — the orthtree's leaf order along its Z-curve, so neighbouring ranks
+ * are spatial neighbours (src/octree/spatial_octree.jl:283 `find_leaf` is the reference's only use of that order). */
+int wtp_block_grid(int nranks, int p_out[3]);
+int wtp_block_morton_rank(int ix, int iy, int iz, const int p[3]);
+/* Grouped point-to-point primitive of the exchange, exposed for callers that drive their own iteration: message j is
+ * sent to and received from rank peers[j], rows of 16 bytes, device buffers, stream-ordered on the context's stream.
+ * Counts must agree on both sides (ncclSend/ncclRecv semantics).  peers[j] may equal the caller's own rank. */
+int wtp_comm_exchange_peers(wtp_ctx* ctx, int n_msgs, const int* peers, const void* const* d_send, const int64_t* n_send,
+                            void* const* d_recv, const int64_t* n_recv);
+/* All-gather of `bytes` bytes per rank between device buffers on the context's stream (bytes a multiple of 8). */
+int wtp_comm_allgather_dev(wtp_ctx* ctx, const void* d_send, void* d_recv, int64_t bytes);
+
 /* Coverage of a sharded session: the caller guarantees that the snapshot holds every point of
  * the global cloud with lo <= coord[axis] <= hi (its slab plus the ghost layers; an end may be
  * +-inf).  A sweep then counts in stats.n_uncovered the movable points whose answer needs more:
@@ -360,7 +446,8 @@ int wtp_relax_set_coverage_box(wtp_ctx* ctx, const double lo[3], const double hi
 
 /* Replace the fixed head of the snapshot by n_fixed_new points (packed 4-vectors in device
  * memory, 4th component ignored).  Movable indices are unchanged; the next wtp_relax_step
- * rebuilds.  Constant spacing only.  */
+ * rebuilds.  Constant spacing or a device-evaluated law (LOGLIKE / BOUNDARY_LAYER: the law is evaluated at the
+ * movable points only, so the new head needs no spacing values); not with a PER_POINT array.  */
 int wtp_relax_set_fixed_dev(wtp_ctx* ctx, const void* d_fixed4, int64_t n_fixed_new);
 
 /* ---- measurement hooks (bench.py, profiles/) -------------------------------------- */

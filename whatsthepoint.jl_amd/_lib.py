@@ -46,6 +46,26 @@ class StepStats(C.Structure):
     ]
 
 
+class BlockDesc(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("nranks", C.c_int32), ("boxes", C.POINTER(C.c_double)),
+                ("ghost_width", C.c_double), ("margin", C.c_double)]
+
+
+class BlockInfo(C.Structure):
+    _fields_ = [("n_owned", C.c_int64), ("n_ghost", C.c_int64), ("n_sent_rows", C.c_int64), ("n_recv_rows", C.c_int64),
+                ("n_emigrated", C.c_int64), ("n_immigrated", C.c_int64), ("n_peers", C.c_int32), ("widened", C.c_int32),
+                ("host_syncs", C.c_int32), ("redone", C.c_int32), ("ghost_width", C.c_double)]
+
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_int64),
+                          C.POINTER(C.c_void_p), C.POINTER(C.c_int64))
+
+
+class Transport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("allgather", ALLGATHER_FN), ("exchange", EXCHANGE_FN)]
+
+
 # every symbol include/wtp.h declares: name -> (restype, argtypes)
 _vp, _i, _i64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_double
 SIGNATURES = {
@@ -100,6 +120,17 @@ SIGNATURES = {
     "wtp_comm_finalize": (_i, [_vp]),
     "wtp_comm_exchange_rows": (_i, [_vp, _i, _i, _vp, _i64, _vp, _i64, _vp, _vp, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
     "wtp_comm_allreduce_stats": (_i, [_vp, C.POINTER(StepStats)]),
+    "wtp_block_set_transport": (_i, [_vp, C.POINTER(Transport)]),
+    "wtp_block_open": (_i, [_vp, C.POINTER(BlockDesc), _vp, _vp, _i64, C.POINTER(SpacingDesc), C.POINTER(ForceDesc), _i, _d, _d]),
+    "wtp_block_step": (_i, [_vp, C.POINTER(StepStats), C.POINTER(BlockInfo)]),
+    "wtp_block_run": (_i, [_vp, _i, _vp, C.POINTER(StepStats), C.POINTER(BlockInfo)]),
+    "wtp_block_run_until": (_i, [_vp, _i, _d, _i, _d, _vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(StepStats)]),
+    "wtp_block_get": (_i, [_vp, _vp, _vp, _i64, C.POINTER(_i64)]),
+    "wtp_block_close": (_i, [_vp]),
+    "wtp_block_grid": (_i, [_i, C.POINTER(_i)]),
+    "wtp_block_morton_rank": (_i, [_i, _i, _i, C.POINTER(_i)]),
+    "wtp_comm_exchange_peers": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_vp), C.POINTER(_i64), C.POINTER(_vp), C.POINTER(_i64)]),
+    "wtp_comm_allgather_dev": (_i, [_vp, _vp, _vp, _i64]),
     "wtp_timers_get": (_i, [_vp, C.POINTER(_d)]),
     "wtp_timers_reset": (_i, [_vp]),
     "wtp_debug_diag": (_i, [_vp, C.POINTER(C.c_ulonglong)]),

@@ -119,6 +119,7 @@ void spans_collect(wtp_ctx* ctx) {
 
 static int sync(wtp_ctx* ctx) {
     ctx->ev_last_end = -1; // the host waits here: whatever it does next is not part of a span
+    ctx->n_syncs += 1;
     WTP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return WTP_OK;
 }
@@ -510,6 +511,7 @@ WTP_API int wtp_create(const int* device_ordinals, int n_dev, wtp_ctx** out) {
 }
 
 WTP_API int wtp_destroy(wtp_ctx* ctx) {
+    if (ctx) block_destroy(ctx);
     if (!ctx) return WTP_OK;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
@@ -1163,8 +1165,8 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
         // (the slot order of P is the sorted order of the last rebuild: the grid groups the points of a wave compactly)
         rc = launch_spacing_session<T>(ctx, (const Pt<T>*)ctx->pts[r.bufP].p, r.n, r.n_fixed, ctx->kd_nodes.p, ctx->kd_m,
                                        r.spacing_kind, r.sp_p0, r.sp_p1, r.sp_p2, (T*)ctx->spacing_pp.p,
-                                       (int32_t*)ctx->sp_hint.p, r.have_tree ? (const int32_t*)ctx->cell_start.p : nullptr,
-                                       ctx->grid.p, getenv("WTP_SP_CERT_OFF") ? nullptr : ctx->sp_cert.p); // (the switch: A/B of the certificates)
+                                       (int32_t*)ctx->sp_hint.p - r.aux_off, r.have_tree ? (const int32_t*)ctx->cell_start.p : nullptr,
+                                       ctx->grid.p, getenv("WTP_SP_CERT_OFF") ? nullptr : (void*)((Pt<T>*)ctx->sp_cert.p - r.aux_off)); // (the switch: A/B of the certificates)
         span_end(ctx, sps);
         if (rc) return rc;
     }
@@ -1252,6 +1254,51 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
 static int relax_step_any(wtp_ctx* ctx, int rebuild, wtp_step_stats* d_slot) {
     return ctx->relax.dtype == WTP_F32 ? relax_step_t<float>(ctx, rebuild, d_slot)
                                        : relax_step_t<double>(ctx, rebuild, d_slot);
+}
+int wtp::relax_step_enqueue(wtp_ctx* ctx, int rebuild, wtp_step_stats* d_slot) { return relax_step_any(ctx, rebuild, d_slot); }
+
+// The movable set of a session is replaced as a whole (block decomposition: points migrated in and out).  The caller
+// writes the new points {x, y, z, bits(index)} into the buffer relax_swap_begin hands out and commits: the session then
+// holds exactly these points, no fixed head, no tree — but keeps what it measured (cell scale, brick geometry, typical
+// spacing), so the next rebuild costs one hash build, not a tuning pass.
+int wtp::relax_swap_begin(wtp_ctx* ctx, int64_t n_move_new, void** d_buf_out) {
+    RelaxState& r = ctx->relax;
+    if (!r.active || r.pending.active) return fail(ctx, WTP_ERR_STATE, "relax_swap_begin: no session, or a pending fixed head");
+    if (n_move_new < 1 || n_move_new > 2000000000LL) return fail(ctx, WTP_ERR_ARG, "relax_swap_begin: bad point count");
+    const size_t ptsz = r.dtype == WTP_F32 ? sizeof(float4) : sizeof(double4);
+    const int t = pick_free(r, r.bufP, -1);
+    int rc;
+    if ((rc = ensure(ctx, ctx->pts[t], ptsz * (size_t)(n_move_new + r.shard_extra)))) return rc;
+    r.swap_target = t;
+    *d_buf_out = ctx->pts[t].p;
+    return WTP_OK;
+}
+
+int wtp::relax_swap_commit(wtp_ctx* ctx, int64_t n_move_new) {
+    RelaxState& r = ctx->relax;
+    if (!r.active || r.swap_target < 0) return fail(ctx, WTP_ERR_STATE, "relax_swap_commit without relax_swap_begin");
+    const size_t ts = tsize(r.dtype);
+    int rc;
+    if (spacing_on_device(r.spacing_kind)) { // hints and certificates belonged to the old set: every point walks once
+        if ((rc = ensure(ctx, ctx->spacing_pp, ts * (size_t)n_move_new))) return rc;
+        if ((rc = ensure(ctx, ctx->sp_hint, sizeof(int32_t) * (size_t)n_move_new))) return rc;
+        if ((rc = ensure(ctx, ctx->sp_cert, 4 * ts * (size_t)n_move_new))) return rc;
+        WTP_HIP(ctx, hipMemsetAsync(ctx->sp_hint.p, 0xFF, sizeof(int32_t) * (size_t)n_move_new, ctx->stream));
+        WTP_HIP(ctx, hipMemsetAsync(ctx->sp_cert.p, 0xFF, 4 * ts * (size_t)n_move_new, ctx->stream));
+        r.aux_off = 0;
+    }
+    r.bufP = r.swap_target;
+    r.swap_target = -1;
+    r.n = n_move_new;
+    r.n_fixed = 0;
+    r.k = (int64_t)r.k_req < n_move_new ? r.k_req : (int)n_move_new;
+    r.bufS = -1;
+    r.bufOld = -1;
+    r.have_tree = false;
+    r.can_revert = false;
+    r.have_point_data = false;
+    r.moved_by_hand = true; // (the kept grid's bounding box is not this set's)
+    return WTP_OK;
 }
 
 WTP_API int wtp_relax_step(wtp_ctx* ctx, int rebuild, wtp_step_stats* stats) {
@@ -1861,8 +1908,8 @@ WTP_API int wtp_relax_set_fixed_dev(wtp_ctx* ctx, const void* d_fixed4, int64_t 
     if (!ctx) return WTP_ERR_ARG;
     RelaxState& r = ctx->relax;
     if (!r.active) return fail(ctx, WTP_ERR_STATE, "wtp_relax_set_fixed_dev before wtp_relax_init");
-    if (r.spacing_kind != WTP_SPACING_CONSTANT)
-        return fail(ctx, WTP_ERR_STATE, "wtp_relax_set_fixed_dev needs a constant spacing");
+    if (r.spacing_kind == WTP_SPACING_PER_POINT)
+        return fail(ctx, WTP_ERR_STATE, "wtp_relax_set_fixed_dev: not with a caller-evaluated (PER_POINT) spacing array");
     if (n_fixed_new < 0 || (n_fixed_new > 0 && !d_fixed4)) return fail(ctx, WTP_ERR_ARG, "bad fixed-point array");
     WTP_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
@@ -1881,6 +1928,13 @@ WTP_API int wtp_relax_set_fixed_dev(wtp_ctx* ctx, const void* d_fixed4, int64_t 
     if ((rc = ensure(ctx, ctx->fb_list, sizeof(int32_t) * (size_t)n_new))) return rc;
     if ((rc = ensure(ctx, ctx->fb2_list, sizeof(int32_t) * (size_t)n_new))) return rc;
     if ((rc = ensure(ctx, ctx->scratch, 64))) return rc;
+    if (spacing_on_device(r.spacing_kind)) {
+        // The law is evaluated at the movable points before every sweep (src/repel.jl:260) and nobody reads a fixed
+        // point's spacing, so the new head needs no values: the array only has to hold n_new entries.  Hints and
+        // certificates stay where they are, addressed by movable index (aux_off follows the head's size).
+        if ((rc = ensure(ctx, ctx->spacing_pp, ts * (size_t)n_new))) return rc; // (contents: rewritten before the next sweep)
+        r.aux_off += n_fixed_new - r.n_fixed;
+    }
     const bool fits = ctx->pts[r.bufP].cap >= ptsz * (size_t)(r.n + n_fixed_new);
     if (fits) {
         // No pass over the cloud: the new head is appended behind the old snapshot and the NEXT hash

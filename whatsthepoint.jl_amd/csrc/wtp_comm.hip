@@ -28,6 +28,7 @@ struct Rccl {
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 
@@ -51,6 +52,7 @@ static int rccl_load(wtp_ctx* ctx) {
     WTP_SYM(Send)
     WTP_SYM(Recv)
     WTP_SYM(AllReduce)
+    WTP_SYM(AllGather)
     WTP_SYM(GetErrorString)
 #undef WTP_SYM
     g_rccl = r;
@@ -209,5 +211,44 @@ WTP_API int wtp_comm_allreduce_stats(wtp_ctx* ctx, wtp_step_stats* st) {
     st->n_fallback = (int64_t)g[5];
     st->n_uncovered = (int64_t)g[6];
     st->n_escaped = (int64_t)g[7];
+    return WTP_OK;
+}
+
+// ---- primitives of the block iteration (wtp_block.hip; also exported) --------------------------------------------------
+// One grouped round: every message is a send to and a receive from peers[j].  Both sides walk their peer lists in
+// ascending rank order and post (send, recv) per peer inside ONE group, so the pairs match without any ordering between
+// different peers; the counts were agreed on beforehand (they ride with the previous iteration's all-gather).
+WTP_API int wtp_comm_exchange_peers(wtp_ctx* ctx, int n_msgs, const int* peers, const void* const* d_send,
+                                    const int64_t* n_send, void* const* d_recv, const int64_t* n_recv) {
+    if (!ctx) return WTP_ERR_ARG;
+    if (!ctx->comm) return fail(ctx, WTP_ERR_STATE, "wtp_comm_exchange_peers before wtp_comm_init");
+    if (n_msgs < 0 || (n_msgs > 0 && (!peers || !d_send || !n_send || !d_recv || !n_recv)))
+        return fail(ctx, WTP_ERR_ARG, "wtp_comm_exchange_peers: NULL argument");
+    for (int j = 0; j < n_msgs; ++j) {
+        if (peers[j] < 0 || peers[j] >= ctx->comm_size) return fail(ctx, WTP_ERR_ARG, "wtp_comm_exchange_peers: peer out of range");
+        if (n_send[j] < 0 || n_recv[j] < 0) return fail(ctx, WTP_ERR_ARG, "wtp_comm_exchange_peers: negative count");
+        if ((n_send[j] > 0 && !d_send[j]) || (n_recv[j] > 0 && !d_recv[j]))
+            return fail(ctx, WTP_ERR_ARG, "wtp_comm_exchange_peers: NULL buffer with a non-zero count");
+    }
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    bool any = false;
+    for (int j = 0; j < n_msgs; ++j) any = any || n_send[j] > 0 || n_recv[j] > 0;
+    if (!any) return WTP_OK;
+    WTP_NCCL(ctx, g_rccl.GroupStart());
+    for (int j = 0; j < n_msgs; ++j) {
+        if (n_send[j] > 0) WTP_NCCL(ctx, g_rccl.Send(d_send[j], (size_t)n_send[j] * 16, ncclUint8, peers[j], comm, ctx->stream));
+        if (n_recv[j] > 0) WTP_NCCL(ctx, g_rccl.Recv(d_recv[j], (size_t)n_recv[j] * 16, ncclUint8, peers[j], comm, ctx->stream));
+    }
+    WTP_NCCL(ctx, g_rccl.GroupEnd());
+    return WTP_OK;
+}
+
+WTP_API int wtp_comm_allgather_dev(wtp_ctx* ctx, const void* d_send, void* d_recv, int64_t bytes) {
+    if (!ctx || !d_send || !d_recv) return WTP_ERR_ARG;
+    if (!ctx->comm) return fail(ctx, WTP_ERR_STATE, "wtp_comm_allgather_dev before wtp_comm_init");
+    if (bytes <= 0 || (bytes & 7)) return fail(ctx, WTP_ERR_ARG, "wtp_comm_allgather_dev: bytes must be a positive multiple of 8");
+    WTP_HIP(ctx, hipSetDevice(ctx->device));
+    WTP_NCCL(ctx, g_rccl.AllGather(d_send, d_recv, (size_t)bytes / 8, ncclUint64, (ncclComm_t)ctx->comm, ctx->stream));
     return WTP_OK;
 }

@@ -182,6 +182,8 @@ struct RelaxState {
     double sp_p0 = 0, sp_p1 = 0, sp_p2 = 0; // LOGLIKE / BOUNDARY_LAYER parameters
     HashView pending;        // wtp_relax_set_fixed_dev left its work to the next rebuild (see there)
     int64_t shard_extra = 0; // extra capacity of the point buffers once the fixed head gets replaced
+    int64_t aux_off = 0;     // device-evaluated spacing laws: sp_hint / sp_cert are stored at [id - aux_off] (a swapped fixed head shifts the movable ids, not the entries)
+    int swap_target = -1;    // relax_swap_begin .. relax_swap_commit (wtp_block.hip: migration)
     bool wall_active = false; // octree method: _constrain_octree runs after every sweep (wtp_relax_set_wall)
     double wall_offset = 0;   // inward nudge of a projected boundary point (src/repel.jl:143)
     int64_t wall_nm = 0;      // movable points the wall arrays are sized for
@@ -260,6 +262,8 @@ struct wtp_ctx {
     int64_t kd_m = 0;          // nodes in it; the key below identifies the boundary it was built from
     uint64_t kd_key = 0;
     int kd_dim = 0, kd_dtype = -1;
+    int64_t n_syncs = 0;       // host synchronisations of the context's stream so far (wtp_block_info.host_syncs counts with it)
+    void* block = nullptr;     // wtp::BlockState (wtp_block.hip): this rank's share of a block-decomposed repel
     void* comm = nullptr;      // ncclComm_t (wtp_comm.hip); rank and size of the communicator
     int comm_rank = 0, comm_size = 0;
     wtp::DevBuf comm_scratch;
@@ -415,6 +419,11 @@ int launch_layers(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int64_t n_fixed, in
                   double lo_out, double hi_out, Pt<T>* d_lo, Pt<T>* d_hi, int64_t cap, int2* d_blk, int32_t* d_totals,
                   bool slot_ordered, double reach);
 template <typename T> int launch_append_fixed(wtp_ctx* ctx, const Pt<T>* d_src, int64_t n, Pt<T>* d_dst);
+// block decomposition (wtp_block.hip) <-> session internals (wtp_api.hip)
+int relax_step_enqueue(wtp_ctx* ctx, int rebuild, wtp_step_stats* d_slot); // one sweep, statistics into a device slot, no synchronisation
+int relax_swap_begin(wtp_ctx* ctx, int64_t n_move_new, void** d_buf_out);  // a free point buffer for a replaced movable set ...
+int relax_swap_commit(wtp_ctx* ctx, int64_t n_move_new);                   // ... which becomes the session's P (no fixed head, tuning kept)
+void block_destroy(wtp_ctx* ctx);                                          // frees ctx->block (wtp_destroy)
 template <typename T>
 int launch_refix(wtp_ctx* ctx, const Pt<T>* in, int64_t n_old, int64_t n_fixed_old, int64_t n_fixed_new,
                  const Pt<T>* d_fixed_new, Pt<T>* out, int32_t* d_counter);
