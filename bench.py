@@ -215,8 +215,34 @@ def other_paths(ctx, torch, np, wtp_amd, extra_legs=False, e2e=True):
     del xe, pe
     if extra_legs:
         _octree_leg(out, ctx, np, wtp_amd, mv, mt, oc, time)
-    _graded_legs(out, ctx, np, wtp_amd, time)
+    _one_gpu_100m_leg(out, ctx, torch, np, wtp_amd)
+    _graded_legs(out, ctx, np, wtp_amd, time, torch)
     return out
+
+
+def _one_gpu_100m_leg(out, ctx, torch, np, wtp_amd):
+    # BASELINE.json configs[3] (100 M points) on ONE GPU: the denominator of the strong-scaling curve the N > 1 runs
+    # of this script report, and the 10^8-cell grid exercised (5 warm-up + 10 timed iterations)
+    n = 100_000_000
+    s = float(n) ** (-1.0 / 3.0)
+    x = torch.empty((n, 3), dtype=torch.float32, device="cuda")
+    ctx.gen_uniform_dev(wtp_amd.synth.SEED, 0, n, 3, np.float32, x.data_ptr())
+    with ctx.relax(None, 0, s, dict(kind=2, beta=0.2, u0=1.0, gamma=3.0), 21, s / 2000, s / 20,
+                   device_ptr=(x.data_ptr(), n, 3, np.float32)) as t:
+        del x
+        t.run_async_free(5, 1)
+        torch.cuda.synchronize()
+        ctx.timers_reset()
+        t0 = time.perf_counter()
+        _, st = t.run(10, 1)
+        dt = (time.perf_counter() - t0) / 10
+        tm = ctx.timers()
+    out["repel_100M_one_gpu"] = {
+        "value": round(n / dt / 1e6, 1), "unit": "Mpoints/s", "ms_per_iter": round(dt * 1e3, 3),
+        "sweep_ms": round(tm["sweep_ms"] / max(tm["sweep_launches"], 1), 3), "hash_ms": round(tm["hash_ms"] / 10, 3),
+        "exact_path_fraction": round(st["n_fallback"] / n, 6),
+        "note": "BASELINE.json configs[3]'s cloud on one MI355X (one-GPU point of the strong-scaling curve)"}
+    torch.cuda.empty_cache()
 
 
 def _octree_leg(out, ctx, np, wtp_amd, mv, mt, oc, time):
@@ -242,11 +268,32 @@ def _octree_leg(out, ctx, np, wtp_amd, mv, mt, oc, time):
     del xo
 
 
-def _graded_legs(out, ctx, np, wtp_amd, time):
+def graded_dev(ctx, torch, np, wtp_amd, n, h_ratio=4.0, delta=0.2):
+    """synth.graded on the device (same stream, same thinning rule; torch float64 instead of numpy, so a borderline
+    acceptance can differ in the last ulp — bench data, not a parity fixture): (n, 3) float32 CUDA tensor."""
+    out, got, first = [], 0, 0
+    while got < n:
+        m = int(min(max(4 * (n - got), 1 << 16), 32_000_000))
+        x = torch.empty((m, 3), dtype=torch.float32, device="cuda")
+        u = torch.empty((m, 1), dtype=torch.float32, device="cuda")
+        ctx.gen_uniform_dev(wtp_amd.synth.SEED, first, m, 3, np.float32, x.data_ptr())
+        ctx.gen_uniform_dev(wtp_amd.synth.SEED + 1, first, m, 1, np.float32, u.data_ptr())
+        first += m
+        xd = x.double()
+        d = torch.minimum(xd, 1.0 - xd).min(dim=1).values
+        sig = 1.0 / (1.0 + torch.exp(-(d - delta / 2) / (delta / 6)))
+        h = 1.0 + (h_ratio - 1.0) * sig
+        keep = u[:, 0].double() < (1.0 / h) ** 3
+        out.append(x[keep])
+        got += int(keep.sum())
+    return torch.cat(out)[:n].contiguous()
+
+
+def _graded_legs(out, ctx, np, wtp_amd, time, torch):
     # graded cloud (BASELINE config 5 / north star "uniform and graded clouds"): thinned uniform stream,
-    # h_bulk/h_wall = 4, with its own BoundaryLayerSpacing law evaluated on the device
-    ng = 1_000_000
-    xg = wtp_amd.synth.graded(ng, 4.0, 0.2, np.float32)
+    # h_bulk/h_wall = 4 (64x density contrast), 10 M points, with its own BoundaryLayerSpacing law evaluated on the device
+    ng = 10_000_000
+    xg = graded_dev(ctx, torch, np, wtp_amd, ng).cpu().numpy()
     shell = int((np.minimum(xg, 1 - xg).min(axis=1) < 0.02).sum())
     hw = float(((1 - 0.96 ** 3) / shell) ** (1.0 / 3.0))
     mg = int(1 / hw)
@@ -268,20 +315,29 @@ def _graded_legs(out, ctx, np, wtp_amd, time):
         t0 = time.perf_counter()
         _, st = t.run(10, 1)
         dt = (time.perf_counter() - t0) / 10
-    out["graded_repel_1M_boundary_layer_law"] = {
+    out["graded_repel_10M_boundary_layer_law"] = {
         "value": round(ng / dt / 1e6, 1), "unit": "Mpoints/s", "ms_per_iter": round(dt * 1e3, 3),
-        "exact_path_fraction": round(st["n_fallback"] / ng, 4),
+        "wall_points": int(len(wall)), "exact_path_fraction": round(st["n_fallback"] / ng, 5),
         "note": "64x density contrast; cell edge measured from the occupancy; points whose support exceeds a cell "
                 "are finished by the ball kernel (wtp_cs2.hip), the rest (exact_path_fraction) by the wave-per-query path; "
-                "the law itself (1-NN in the boundary kd-tree, every sweep) is now the largest piece (DESIGN.md §4)"}
-    ctx.timers_reset()
-    t0 = time.perf_counter()
-    off, _ = ctx.radius(xg, 2.5 * hw)
-    dt = time.perf_counter() - t0
-    tm = ctx.timers()
-    out["graded_radius_topology_1M"] = {"value": round(ng / dt / 1e6, 1), "unit": "Mpoints/s", "ms": round(dt * 1e3, 2),
-                                        "kernel_ms": round(tm["hash_ms"] + tm["sweep_ms"] + tm["other_ms"], 3),
-                                        "pairs": int(off[-1]), "note": "r = 2.5 h_wall, host arrays in and out"}
+                "the law (1-NN in the boundary kd-tree) is evaluated at every movable point before every sweep"}
+    # RadiusTopology on the same cloud (fp32 and fp64), r = 2.5 h_wall
+    for name, xx in (("f32", xg), ("f64", xg.astype(np.float64))):
+        ctx.radius(xx[:200000], 2.5 * hw)
+        ctx.timers_reset()
+        t0 = time.perf_counter()
+        off, _ = ctx.radius(xx, 2.5 * hw)
+        dt = time.perf_counter() - t0
+        tm = ctx.timers()
+        kms = tm["hash_ms"] + tm["sweep_ms"] + tm["other_ms"]
+        pairs = int(off[-1])
+        bpp = 4 if name == "f32" else 8
+        alg = (50.0 * bpp / 4 + 4 * bpp + 1 + 8) * ng + 4.0 * pairs  # hash + sweep read + count + offset, + the rows
+        out[f"graded_radius_topology_10M_{name}"] = {
+            "value": round(ng / dt / 1e6, 1), "unit": "Mpoints/s", "ms": round(dt * 1e3, 2), "kernel_ms": round(kms, 3),
+            "pairs": pairs, "kernel_alg_gbs": round(alg / (kms * 1e-3) / 1e9, 1) if kms > 0 else None,
+            "note": "r = 2.5 h_wall, host arrays in and out (value / ms include PCIe), kernel_ms is the device time"}
+        del off
 
 
 def self_launch(n: int) -> int:
@@ -304,6 +360,8 @@ def self_launch(n: int) -> int:
                 env0["WTP_BENCH_REHEARSAL"] = "1"
         except Exception:
             pass
+    if env0.get("WTP_BENCH_REHEARSAL") == "1" and (n > 4 or os.environ.get("WTP_BENCH_THREADS") == "1"):
+        return None  # too many processes for one GPU: the ranks run as threads of this process (rehearse_threads)
     procs = []
     for r in range(n):
         env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
@@ -312,6 +370,69 @@ def self_launch(n: int) -> int:
     for pr in procs:
         rc = max(rc, pr.wait())
     return rc
+
+
+def rehearse_threads(args) -> int:
+    """--gpus N on a box with fewer GPUs, N > 4: the N ranks are threads of this process, one libwtp context each on
+    GPU 0, rows carried by the loopback transport of the C block driver (wtp_block_set_transport).  Exercises the whole
+    N-rank iteration (exchange plan, migration, statistics gather); the number it prints is NOT a scaling point."""
+    import threading
+
+    import numpy as np
+    import torch
+
+    import wtp_amd
+    from whatsthepoint_jl_amd import blockc, sharded
+
+    world = args.gpus
+    n_total = args.total_points or min(100_000_000, 2_000_000 * world)
+    s = float(n_total) ** (-1.0 / 3.0)
+    force = dict(kind=2, beta=0.2, u0=1.0, gamma=3.0)
+    boxes = blockc.orthtree_boxes(None, world, equal_count=False)
+    gate = threading.Barrier(world)
+    times, infos = [0.0] * world, [None] * world
+
+    def worker(rank, hub):
+        torch.cuda.set_device(0)
+        ctx = wtp_amd.Context(0)
+
+        def gen(first, n):
+            t = torch.empty((n, 3), dtype=torch.float32, device="cuda")
+            ctx.gen_uniform_dev(wtp_amd.synth.SEED, first, n, 3, np.float32, t.data_ptr())
+            return t
+
+        xyz, gid = blockc.shard_stream(gen, boxes, rank, n_total)
+        drv = blockc.BlockRelax(ctx, rank, world, boxes, xyz, gid, sharded.ghost_width(n_total, 21, ctx_rho()), s, force, 21,
+                                s / 2000, s / 20, transport=blockc.loopback_transport(hub, rank))
+        drv.run(args.warmup)
+        torch.cuda.synchronize()
+        gate.wait()
+        t0 = time.perf_counter()
+        out = drv.run(args.steps)
+        torch.cuda.synchronize()
+        gate.wait()
+        times[rank] = time.perf_counter() - t0
+        infos[rank] = out
+        drv.close()
+        ctx.close()
+        return out
+
+    blockc.run_threads(world, worker)
+    dt = max(times)
+    g = blockc.block_grid(world)
+    print(json.dumps({
+        "metric": "Mpoints/sec per repel iter (k=21 KNN+force)", "value": round(n_total * args.steps / dt / 1e6, 3),
+        "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{n_total} uniform fp32 points in the unit cube, repel sweep k=21 (BASELINE.json configs[3] scaled to one GPU)",
+                   "points_per_gpu": n_total // world,
+                   "sharding": f"{g[0]} x {g[1]} x {g[2]} orthtree boxes, C block driver (wtp_block_*), REHEARSAL: {world} ranks as "
+                               f"threads of one process sharing ONE GPU, rows staged through host memory — not a scaling point"},
+        "roofline": None, "cpu_baseline": None,
+        "block_info": {k: int(v) for k, v in infos[0].items() if k in ("n_owned", "n_ghost", "n_peers", "widened", "host_syncs")},
+    }), flush=True)
+    return 0
 
 
 def ctx_rho() -> float:
@@ -340,7 +461,8 @@ def main():
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(self_launch(args.gpus))  # nothing has touched a GPU yet
+        rc = self_launch(args.gpus)  # nothing has touched a GPU yet
+        raise SystemExit(rehearse_threads(args) if rc is None else rc)
 
     # the CPU oracle is built / loaded (a compiler run when the shipped .so looks stale) BEFORE the GPU is
     # initialised: no child processes from a GPU-initialised process
@@ -382,7 +504,7 @@ def main():
 
     if world == 1:
         n_total = n_local = args.points
-        scaling = "weak"  # (one GPU: the label is moot)
+        scaling = "none"  # one GPU: nothing is scaled
     elif args.weak:
         n_local, n_total, scaling = args.points, args.points * world, "weak"
     else:
@@ -409,8 +531,38 @@ def main():
             ctx.gen_uniform_dev(wtp_amd.synth.SEED, first, n, 3, np.float32, t.data_ptr())
             return t
 
-        slabs = os.environ.get("WTP_SHARD", "blocks") == "slabs"
-        if slabs:  # the round-1 decomposition: z-slabs, two neighbours
+        shard = os.environ.get("WTP_SHARD", "blockc")
+        slabs = shard == "slabs"
+        if shard == "blockc":  # round 3 default: the whole iteration in C (wtp_block_*), one grouped exchange round
+            from whatsthepoint_jl_amd import blockc
+
+            boxes = blockc.orthtree_boxes(None, world, equal_count=False)
+            own_xyz, own_gid = blockc.shard_stream(gen, boxes, rank, n_total)
+            transport = None
+            if rehearsal:
+                transport = blockc.dist_transport(dist, rank, world)
+            else:  # the context's own RCCL communicator; torch only carries the 128-byte id
+                box = [ctx.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                ctx.comm_init(box[0], rank, world)
+            cdrv = blockc.BlockRelax(ctx, rank, world, boxes, own_xyz, own_gid, sharded.ghost_width(n_total, k, ctx_rho()), s,
+                                     force, k, s / 2000, s / 20, transport=transport)
+            del own_xyz, own_gid
+            g3 = blockc.block_grid(world)
+            shard_note = (f"{g3[0]} x {g3[1]} x {g3[2]} orthtree boxes (Morton rank order), C block driver: one grouped "
+                          f"send/recv round per iteration, counts riding the statistics all-gather")
+
+            class _Drv:
+                last = None
+
+                def run(self, iters):
+                    self.last = cdrv.run(iters)
+
+                def points_per_launch(self):
+                    return int(self.last["n_owned"] + self.last["n_ghost"])
+
+            drv = _Drv()
+        elif slabs:  # the round-1 decomposition: z-slabs, two neighbours
             own_xyz, own_gid, cuts = sharded.uniform_shard(gen, rank, world, n_total, wtp_amd.synth.SEED, "cuda")
             drv = sharded.ShardedRelax(sharded.GpuEngine(ctx, s, force, k, s / 2000, s / 20), dist, own_xyz, own_gid, cuts,
                                        sharded.ghost_width(n_total, k, ctx_rho()),
@@ -551,11 +703,13 @@ def main():
                 print(f"[bench] copy-bandwidth probe failed: {e}", file=sys.stderr)
         # HBM bytes per launch come from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 on
         # gfx950 + WRITE_SIZE), scaled to this launch's point count; counters cannot be read live.
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
+        if not os.path.exists(tpath):
+            tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             out["roofline"]["traffic"] = round(tj["traffic_bytes_per_launch"] * pts_per_launch / tj["points_per_launch"])
-            out["roofline"]["traffic_source"] = "profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
+            out["roofline"]["traffic_source"] = f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"
             out["roofline"]["algorithmic_bytes"] = round(B_ALG_SWEEP * pts_per_launch)
             if "valu_wave_instructions_per_launch" in tj and sweep_ms > 0:
                 # what actually bounds the kernel: vector-ALU issue.  Wave instructions per launch from
@@ -568,7 +722,7 @@ def main():
                                      "peak": 39.3, "unit": "T lane-ops/s", "frac": round(ops / (sweep_ms * 1e-3) / 39.3e12, 3),
                                      "lane_ops_per_point": round(ops / pts_per_launch, 1),
                                      "all_instructions_per_point": tj.get("all_wave_instructions_per_launch", 0) * 64.0 / tj["points_per_launch"],
-                                     "source": "profiles/r02_traffic.json (rocprofv3 --pmc SQ_INSTS_VALU, _SALU, _LDS, _VMEM)"}
+                                     "source": f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc SQ_INSTS_VALU, _SALU, _LDS, _VMEM)"}
         if full_sel is not None:
             out["full_k_selection_path"] = full_sel
         if world == 1 and not args.no_other_paths:

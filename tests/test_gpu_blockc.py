@@ -193,3 +193,36 @@ def test_octants_two_million_points(wtp):
     conv = np.array([h["max_force"] for h in hists[0]])
     assert np.allclose(conv, conv0, rtol=1e-5)
     assert sum(h["n_emigrated"] for hh in hists for h in hh) > 100
+
+
+def _bench_line(args, env_extra=None):
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WTP_BENCH_REHEARSAL="1", **(env_extra or {}))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, env=env,
+                         timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_rehearsal_two_processes_over_gloo():
+    """bench.py --gpus 2 on the one-GPU box: two rank processes, the C block driver over the host-callback transport
+    (torch.distributed gloo), fixed total => "scaling": "strong"."""
+    out = _bench_line(["--gpus", "2", "--steps", "4", "--warmup", "2", "--total-points", "600000", "--no-cpu"])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    assert "C block driver" in out["config"]["sharding"]
+
+
+def test_bench_rehearsal_eight_ranks_as_threads():
+    """bench.py --gpus 8 in rehearsal mode: eight ranks as threads sharing the GPU."""
+    out = _bench_line(["--gpus", "8", "--steps", "4", "--warmup", "2", "--total-points", "1600000", "--no-cpu"])
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["block_info"]["n_peers"] == 7

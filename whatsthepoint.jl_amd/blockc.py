@@ -97,6 +97,30 @@ def owner_of(xyz: np.ndarray, boxes: np.ndarray) -> np.ndarray:
     return own
 
 
+def shard_stream(gen, boxes, rank: int, n_total: int, chunk: int = 8_000_000):
+    """This rank's box of a synthetic cloud that exists as a global stream: gen(first, n) -> (n, 3)
+    float32 CUDA tensor; the stream is generated in chunks and filtered, so global ids equal the single-GPU run's
+    point indices.  Returned in cell order (the library hands points back in the order it got them, so every later
+    rebuild reads a nearly sorted array)."""
+    import torch
+
+    b = torch.tensor(np.asarray(boxes[rank], dtype=np.float32))
+    xs, gs = [], []
+    for first in range(0, n_total, chunk):
+        n = min(chunk, n_total - first)
+        x = gen(first, n)
+        m = torch.ones(n, dtype=torch.bool, device=x.device)
+        for a in range(3):
+            m &= (x[:, a] >= float(b[a])) & (x[:, a] < float(b[3 + a]))
+        xs.append(x[m])
+        gs.append(torch.nonzero(m).reshape(-1).to(torch.int64) + first)
+    xyz, gid = torch.cat(xs).contiguous(), torch.cat(gs).contiguous()
+    cell = max((float(n_total) ** (-1.0 / 3.0)) * 2.0, 1e-6)
+    key = torch.floor(xyz / cell).to(torch.int64)
+    order = torch.argsort((key[:, 2] * 4096 + key[:, 1]) * 4096 + key[:, 0], stable=True)
+    return xyz[order].contiguous(), gid[order].contiguous()
+
+
 class BlockRelax:
     """This rank's share of a block-decomposed repel, driven through wtp_block_* (the iteration is C).
     owned_xyz / gid: torch CUDA tensors (n, 3) float32 / (n,) int64 on the context's device, or numpy arrays
