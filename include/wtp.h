@@ -172,8 +172,15 @@ int wtp_relax_run(wtp_ctx* ctx, int n_iters, int rebuild_every, double* conv_out
 /* The loop of `_relax!` WITH its stop rules (src/repel.jl:305-334), evaluated on the device after every sweep in the
  * reference's order: cv_target (positions are then reverted to p_old, :314), stall_after on the CV of d_NN / s
  * (:316-326), tol on max |F| s (:329-332).  Sweeps are enqueued in batches of 16 without any host round trip; once a
- * rule fires the rest of the batch does nothing, so the session ends in exactly the state of the reference's last
- * iteration.  conv_out[0 .. *n_done) = max |F| s per sweep; *reason: 0 max_iters reached, 1 tol, 2 cv_target, 3 stall.
+ * rule fires the rest of the batch does nothing, so the session ends in the state of the last iteration that ran.
+ * The CV is evaluated from sums of u = d_NN / s and u^2 accumulated in DOUBLE (u itself is rounded in the cloud's
+ * type).  The reference's `_dnn_cv` (src/repel.jl:374-386) sums serially in the cloud's type T: for Float64 clouds the
+ * two agree to rounding and the loop stops at the reference's iteration (tests/test_gpu_stop_rules.py: same count,
+ * reason and positions as the oracle's loop); for Float32 clouds a serial Float32 sum over >= 10^4 points carries
+ * 1e-4 .. 1e-3 relative error in the variance — the size of the stall rule's own 1e-3 margin — so the reference's
+ * stall / cv_target rule can fire at ANOTHER iteration than this one (which uses the better number).  tol is
+ * unaffected (a maximum).  conv_out[0 .. *n_done) = max |F| s per sweep; *reason: 0 max_iters reached, 1 tol,
+ * 2 cv_target, 3 stall.
  * Not for sessions with the octree wall rule (wtp_relax_set_wall), kicks, traces or a caller-evaluated spacing:
  * those need the host between two sweeps (wtp_relax_step).  */
 int wtp_relax_run_until(wtp_ctx* ctx, int max_iters, int rebuild_every, double tol, int stall_after, double cv_target,

@@ -221,6 +221,12 @@ def _relax_loop_callable(snap, n_fixed, spacing, force_kind, beta, u0, gamma, k,
     return dict(p=p, conv=conv[:nconv].copy(), stop_reason=int(reason.value))
 
 
+def set_cv_double(on: bool):
+    """Test switch of the loop's CV monitor: rules on double sums (what the device evaluates) instead of sums in the
+    cloud's float type (what the reference evaluates, src/repel.jl:374-386)."""
+    lib().wtpo_set_cv_double(C.c_int(1 if on else 0))
+
+
 def dnn_cv(nn_dist, spacings, n_fixed: int):
     nn_dist = np.ascontiguousarray(nn_dist)
     dt = nn_dist.dtype

@@ -36,6 +36,14 @@
 #include <string.h>
 #include <float.h>
 
+/* Test switch: the CV monitor of the loop (src/repel.jl:374-386) evaluated from DOUBLE sums instead of sums in the
+ * cloud's float type.  The reference sums serially in T; the device path sums in double (wtp.h: wtp_relax_run_until), which
+ * for Float32 clouds is the better number and can fire a stall / cv_target rule at another iteration.  With the switch on,
+ * the oracle's loop applies the rules to the same quantity the device does, so the two can be compared exactly; with it
+ * off it is the reference's arithmetic, and tests record how often that differs. */
+static int g_cv_double = 0;
+void wtpo_set_cv_double(int on) { g_cv_double = on; }
+
 #define REAL float
 #define SUF f32
 #define SQRT sqrtf

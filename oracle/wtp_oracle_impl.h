@@ -611,7 +611,7 @@ int FN(wtpo_relax_loop_cb)(REAL* snap, int64_t n, int64_t n_fixed, int dim, REAL
     REAL* forces = (REAL*)malloc(sizeof(REAL) * (size_t)(n_move + 1));
     REAL* nn_dist = (REAL*)malloc(sizeof(REAL) * (size_t)(n_move + 1));
     int32_t* nn_id = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n_move + 1));
-    REAL best_cv = (REAL)INFINITY; /* typemax(U) :238 */
+    double best_cv = INFINITY; /* typemax(U) :238 (held in double: a REAL value converts exactly) */
     int last_impr = 0, nconv = 0, i = 1;
     *stop_reason = 0;
     while (i <= max_iters) {
@@ -628,7 +628,14 @@ int FN(wtpo_relax_loop_cb)(REAL* snap, int64_t n, int64_t n_fixed, int dim, REAL
             if (forces[t] > mx) mx = forces[t];
         conv[nconv++] = mx;
         if ((stall_after > 0 || cv_target > 0) && n_move > 0) { /* :305-327 */
-            REAL cv = FN(wtpo_dnn_cv)(nn_dist, spacings, n_move, n_fixed, NULL, NULL);
+            double su = 0, su2 = 0;
+            double cv = (double)FN(wtpo_dnn_cv)(nn_dist, spacings, n_move, n_fixed, &su, &su2);
+            if (g_cv_double) { /* test switch (wtp_oracle.c): the rule on double sums, as the device evaluates it */
+                const double mu = su / (double)n_move;
+                double var = su2 / (double)n_move - mu * mu;
+                var = var > 0 ? var : 0;
+                cv = sqrt(var) / mu;
+            }
             if (cv_target > 0 && (double)cv <= cv_target) {
                 memcpy(p, p_old, sizeof(REAL) * (size_t)(n_move * dim)); /* :314 */
                 *stop_reason = 2;
