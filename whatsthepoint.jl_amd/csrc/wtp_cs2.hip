@@ -45,10 +45,9 @@ constexpr int kCsThreads = 256;
 constexpr int kCsSlab = 16;                         // halo cells per x index: (2+2) x (2+2)
 constexpr int kCsMaxBX = 61;                        // own cells along x; halo + the closing column <= 64 lanes
 constexpr int kCsMaxCells = (kCsMaxBX + 2) * kCsSlab;
-constexpr int kCsRing = 24;                         // ring entries per lane (hits inside the support; > k of them -> exact path)
-constexpr int kCsRingStride = 36;                   // bytes per lane: 24 entries + 8 a scan step may still store + pad; 9 dwords: odd, so lanes spread over the banks
+constexpr int kCsMaskSteps = 12;                    // scan steps the three hit-mask registers hold (96 slots of a run)
 constexpr int kCsSU = 8;                            // candidates per scan step
-constexpr int kCsPadBytes = kCsSU * 16;
+constexpr int kCsPadBytes = 2 * kCsSU * 16;          // far sentinels behind the staged points: a run's last step and the half step read ahead of it
 constexpr int kCsMaxQ = 512;                        // queries per brick the lane table covers
 constexpr int kCsMiss = 16;                         // empty-support queries per wave per brick
 constexpr int kCsRun = 2 * kCsSlab + 2 * 4 + 3;     // halo cells in a query's run: 43
@@ -150,15 +149,14 @@ __device__ inline float4 cs_pt(const unsigned char* base, uint32_t byte_off) {
 }
 
 static size_t cs2_smem_bytes(int hcap) {
-    return (size_t)hcap * 16 + kCsPadBytes + (size_t)kCsRingStride * kCsThreads + sizeof(Cs2Smem);
+    return (size_t)hcap * 16 + kCsPadBytes + sizeof(Cs2Smem);
 }
 
 __global__ __launch_bounds__(kCsThreads, 4) void cs2_kernel(SearchArgs<float> a, int hcap, int BX) {
     if (a.stop && *a.stop) return; // wtp_relax_run_until: a stop rule fired earlier in this batch
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float4* pts = reinterpret_cast<float4*>(smem_raw);
-    const uint32_t ring_off = (uint32_t)hcap * 16u + (uint32_t)kCsPadBytes;
-    Cs2Smem* sm = reinterpret_cast<Cs2Smem*>(smem_raw + ring_off + (size_t)kCsRingStride * kCsThreads);
+    Cs2Smem* sm = reinterpret_cast<Cs2Smem*>(smem_raw + (size_t)hcap * 16 + kCsPadBytes);
     const int tid = threadIdx.x, lane = tid & 63;
     // wave-uniform by construction; saying so keeps the per-row geometry and the row bounds in scalar registers
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -355,7 +353,7 @@ __global__ __launch_bounds__(kCsThreads, 4) void cs2_kernel(SearchArgs<float> a,
             // one scan step past the staged points: far sentinels instead of another brick's leftovers
             // (a run's last step reads up to 7 slots past its end; every CELL past a run is two cells
             // away from the query, so only the slots past the last cell need this)
-            if (tid < kCsSU) pts[halo_total + tid] = make_float4(1e30f, 1e30f, 1e30f, 0.f);
+            if (tid < 2 * kCsSU) pts[halo_total + tid] = make_float4(1e30f, 1e30f, 1e30f, 0.f);
         }
         // the next brick: its cell table has arrived by now, its points fly while this brick's queries run
 #pragma unroll
@@ -440,102 +438,148 @@ __global__ __launch_bounds__(kCsThreads, 4) void cs2_kernel(SearchArgs<float> a,
             // candidate run: halo cells P(hx-1, hz-1, hy-1) .. P(hx+1, hz+1, hy+1), contiguous in LDS
             const int Pf = (hx - 1) * kCsSlab + (hz - 1) * 4 + (hy - 1);
             const uint32_t pa0 = (uint32_t)sm->ls[Pf] * 16u, ea = (uint32_t)sm->ls[Pf + kCsRun] * 16u;
-            // ring: one byte per hit = slot index inside the run; runs beyond 255 slots (dense cluster) give up
-            bool giveup = (ea - pa0) > 255u * 16u;
-            float tau_s = (cs_fail || giveup) ? -1.f : lim * (1.f + 0x1p-21f); // FMA filter, 4 ulp wide; the ring pass is exact
-            const uint32_t ring_b = ring_off + (uint32_t)tid * (uint32_t)kCsRingStride;
+            // Hits are kept as a bit mask of the run's slots in three registers (96 slots = 12 steps; longer runs, a dense
+            // cluster, give up): the scan loop then holds no LDS store at all.  Round 2 appended a byte per hit to a ring in
+            // LDS — one ds_write_b8 (4 LDS cycles) next to every ds_read_b128 (4 + bank conflicts), which made the scan
+            // LDS-bound: 4 waves x ~11 LDS cycles per candidate against 4 x ~10 VALU cycles on four SIMDs in parallel.
+            bool giveup = (ea - pa0) > (uint32_t)(kCsMaskSteps * kCsSU) * 16u;
+            const uint32_t ea_s = giveup ? pa0 : ea; // (a lane that gave up must not prolong the wave's loop: the masks hold 12 steps)
+            const float tau_s = (cs_fail || giveup) ? -1.f : lim * (1.f + 0x1p-21f); // FMA filter, 4 ulp wide; the force pass is exact
             const uint32_t lds_base = (uint32_t)(uintptr_t)smem_raw;
-            const uint32_t ring_a = lds_base + ring_b; // LDS address of this lane's ring
-            uint32_t ra = ring_a; // next free ring byte (the running address itself: one add-with-carry per candidate)
+            uint32_t m0 = 0, m1 = 0, m2 = 0; // slot i of the run = bit (8 S - 1 - i) of m2:m1:m0 after S steps
             CS_STAMP(1) // query setup
             if (WTP_DIAG) {
                 dt[9] += 1;                                           // query rounds (per wave)
                 dt[10] += (unsigned long long)__popcll(__ballot(true)); // queries
             }
-            uint32_t idx0 = 0; // slot index of the step's first candidate inside the run
-            for (uint32_t pa = pa0; __any(pa < ea); pa += 16u * kCsSU, idx0 += kCsSU) {
-                if (WTP_DIAG) {
-                    dt[11] += 1; // scan steps (per wave)
-                    dt[12] += (unsigned long long)__popcll(__ballot(pa < ea)); // busy lanes
-                }
-                if (__any(ra > ring_a + (uint32_t)kCsRing)) { // a lane's ring is full (dense cluster): that lane gives up
-                    if (ra > ring_a + (uint32_t)kCsRing) {
-                        giveup = true;
-                        ra = ring_a;
-                        tau_s = -1.f;
+            int S = 0;
+            {
+                // Software pipeline over half steps of four candidates: a register group is refilled (ds_read_b128 into the
+                // same registers) as soon as its three subtractions have consumed it, and a use waits only for ITS read
+                // (LDS returns in order: `lgkmcnt(3)` = everything but the three youngest reads has landed).  The wave no
+                // longer drains the LDS queue before every group of four.
+                cs_f4 c[4];
+                uint32_t pa = pa0;
+                uint32_t addr = lds_base + pa0;
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48"
+                             : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3])
+                             : "v"(addr)
+                             : "memory");
+#define CS_WAIT3(reg) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(reg)::"memory")
+#define CS_REFILL(reg, a, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(reg) : "v"(a), "n"(off) : "memory")
+                // compare, then mask = 2 mask + hit: one add-with-carry per candidate
+#define CS_TEST(dist)                                                                     \
+    asm volatile("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" \
+                 : "+v"(hb)                                                                \
+                 : "v"(dist), "v"(thr)                                                     \
+                 : "vcc")
+                for (;;) {
+                    if (WTP_DIAG) {
+                        dt[11] += 1; // scan steps (per wave)
+                        dt[12] += (unsigned long long)__popcll(__ballot(pa < ea_s)); // busy lanes
                     }
-                }
-                // a lane whose run has ended keeps reading its first slots with an impossible threshold.  Inside a
-                // run no end mask is needed: the slots a last step reads past the run's end belong to cells two
-                // away from the query (or are the sentinels behind the last cell) and fail the distance test.
-                const bool busy = pa < ea;
-                const float thr = busy ? tau_s : -1.f;
-                const uint32_t addr = lds_base + (busy ? pa : pa0);
-                cs_f4 c[4]; // two half steps: 16 registers of candidates instead of 32 (the next brick's loads sit in registers too)
-                // append = compare, unconditional byte store at the running ring address, add-with-carry of the
-                // compare's bit to that address: three instructions per candidate besides the six of the distance
-                // (written out: the compiler turns `ra += take` into select + add, one instruction more per candidate)
-#define CS_APPEND(dist, val)                                                                            \
-    asm volatile("v_cmp_le_f32 vcc, %1, %2\n\tds_write_b8 %0, %3\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" \
-                 : "+v"(ra)                                                                              \
-                 : "v"(dist), "v"(thr), "v"(val)                                                         \
-                 : "vcc", "memory")
-                cs_read_group<0>(c, addr);
+                    // a lane whose run has ended keeps reading its first slots with an impossible threshold.  Inside a
+                    // run no end mask is needed: the slots a last step reads past the run's end belong to cells two
+                    // away from the query (or are the sentinels behind the last cell) and fail the distance test.
+                    const float thr = pa < ea_s ? tau_s : -1.f;
+                    const uint32_t pn = pa + 16u * kCsSU;
+                    const uint32_t addr_n = lds_base + (pn < ea_s ? pn : pa0); // what the NEXT step reads
+                    uint32_t hb = 0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float ex = qp.x - c[u].x, ey = qp.y - c[u].y, ez = qp.z - c[u].z;
-                    const float d = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
-                    const uint32_t val = idx0 + (uint32_t)u; // slot index inside the run; rewritten or never read when not taken
-                    CS_APPEND(d, val);
-                }
-                cs_read_group<64>(c, addr);
+                    for (int u = 0; u < 4; ++u) { // slots 0..3; the group is refilled with slots 4..7 of this step
+                        CS_WAIT3(c[u]);
+                        const float ex = qp.x - c[u].x, ey = qp.y - c[u].y, ez = qp.z - c[u].z;
+                        switch (u) {
+                            case 0: CS_REFILL(c[0], addr, 64); break;
+                            case 1: CS_REFILL(c[1], addr, 80); break;
+                            case 2: CS_REFILL(c[2], addr, 96); break;
+                            default: CS_REFILL(c[3], addr, 112); break;
+                        }
+                        const float d = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
+                        CS_TEST(d);
+                    }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float ex = qp.x - c[u].x, ey = qp.y - c[u].y, ez = qp.z - c[u].z;
-                    const float d = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
-                    const uint32_t val = idx0 + 4u + (uint32_t)u;
-                    CS_APPEND(d, val);
+                    for (int u = 0; u < 4; ++u) { // slots 4..7; refilled with slots 0..3 of the next step
+                        CS_WAIT3(c[u]);
+                        const float ex = qp.x - c[u].x, ey = qp.y - c[u].y, ez = qp.z - c[u].z;
+                        switch (u) {
+                            case 0: CS_REFILL(c[0], addr_n, 0); break;
+                            case 1: CS_REFILL(c[1], addr_n, 16); break;
+                            case 2: CS_REFILL(c[2], addr_n, 32); break;
+                            default: CS_REFILL(c[3], addr_n, 48); break;
+                        }
+                        const float d = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
+                        CS_TEST(d);
+                    }
+                    m2 = __builtin_amdgcn_alignbit(m2, m1, 24);
+                    m1 = __builtin_amdgcn_alignbit(m1, m0, 24);
+                    m0 = (m0 << 8) | hb;
+                    ++S;
+                    pa = pn;
+                    addr = addr_n;
+                    if (!__any(pa < ea_s)) break;
                 }
-#undef CS_APPEND
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])::"memory"); // the reads issued for a step that does not come
+#undef CS_WAIT3
+#undef CS_REFILL
+#undef CS_TEST
             }
-            const uint32_t cnt = ra - ring_a;
+            S = __builtin_amdgcn_readfirstlane(S);
             CS_STAMP(2) // scan
 
-            // ---- ring pass: canonical d2 of every survivor, exact cut, force sum (src/repel.jl:270-280) ----
+            // ---- force pass: canonical d2 of every hit, exact cut, force sum (src/repel.jl:270-280) ----
+            // Hits are taken off the mask words from the top (v_ffbh), two per trip; a lane whose word is empty reads its
+            // own point instead, which the self-exclusion by index (src/repel.jl:271) drops like the self hit itself.
             const ForceCoefCs fc = force_coef_cs(a.beta, a.u0);
-            int n_lim = 0;
+            int n_oth = 0; // points other than the query inside the support (the query itself is always there)
             bool coincident = false;
             float Fx = 0.f, Fy = 0.f, Fz = 0.f;
             int32_t nid = 0x7FFFFFFF;
             float nd2 = Lim<float>::inf();
-            for (uint32_t j0 = 0; __any(j0 < cnt); j0 += 4) {
-                if (WTP_DIAG) dt[13] += 1; // ring batches (per wave)
-                const uint32_t e4 = *reinterpret_cast<const uint32_t*>(smem_raw + ring_b + j0); // four entries
-                float4 c[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t e = (j0 + u) < cnt ? ((e4 >> (8 * u)) & 0xFFu) : 0u;
-                    c[u] = cs_pt(smem_raw, pa0 + e * 16u);
+            auto visit = [&](const float4& c) {
+                const float dx = qp.x - c.x, dy = qp.y - c.y, dz = qp.z - c.z;
+                const float d = (dx * dx + dy * dy) + dz * dz;
+                const int32_t cid = w_to_id(c.w);
+                const bool act = (d <= lim) & (cid != qid);
+                n_oth += act ? 1 : 0;
+                const bool nearer = act & ((d < nd2) | ((d == nd2) & (cid < nid)));
+                nd2 = nearer ? d : nd2;
+                nid = nearer ? cid : nid;
+                // f(u) / r with one reciprocal square root: (A - u2) / ((u2 + beta)^2 sqrt(d)) = (A - u2) rsq(d (u2 + beta)^4)
+                const float u2 = d * inv_s2, t = u2 + fc.beta, t2 = t * t;
+                const float r = __builtin_amdgcn_rsqf((d * t2) * t2);
+                const float f = fmaxf(fc.A - u2, 0.f) * r;
+                const bool pos = d > 0.f;
+                const float coef = (act & pos) ? f : 0.f;
+                Fx = __builtin_fmaf(coef, dx, Fx); // (this path's sum order differs from the reference's anyway)
+                Fy = __builtin_fmaf(coef, dy, Fy);
+                Fz = __builtin_fmaf(coef, dz, Fz);
+                coincident = coincident | (act & !pos);
+            };
+            auto word_pass = [&](uint32_t mw, int top_slot) { // top_slot: the run slot of the word's bit 31
+                const uint32_t base_w = pa0 + (uint32_t)(top_slot * 16); // byte offset of that slot in the point area
+                while (__any(mw != 0u)) {
+                    if (WTP_DIAG) dt[13] += 1; // force-pass trips (per wave)
+                    // v_ffbh_u32 gives -1 for an empty word: the shift below then clears bit 0 (clear already) and the
+                    // address is replaced by the query's own slot
+                    uint32_t l1, l2;
+                    const bool v1 = mw != 0u;
+                    asm("v_ffbh_u32 %0, %1" : "=v"(l1) : "v"(mw));
+                    const uint32_t o1 = v1 ? base_w + (l1 << 4) : qoff;
+                    mw &= ~(0x80000000u >> (l1 & 31u));
+                    const bool v2 = mw != 0u;
+                    asm("v_ffbh_u32 %0, %1" : "=v"(l2) : "v"(mw));
+                    const uint32_t o2 = v2 ? base_w + (l2 << 4) : qoff;
+                    mw &= ~(0x80000000u >> (l2 & 31u));
+                    const float4 c1 = cs_pt(smem_raw, o1), c2 = cs_pt(smem_raw, o2);
+                    visit(c1);
+                    visit(c2);
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float dx = qp.x - c[u].x, dy = qp.y - c[u].y, dz = qp.z - c[u].z;
-                    const float d = (dx * dx + dy * dy) + dz * dz;
-                    const int32_t cid = w_to_id(c[u].w);
-                    const bool inl = ((j0 + u) < cnt) && (d <= lim);
-                    n_lim += inl ? 1 : 0;
-                    const bool act = inl && (cid != qid); // self skipped by index (src/repel.jl:271)
-                    const bool nearer = act && lex_lt(d, cid, nd2, nid);
-                    nd2 = nearer ? d : nd2;
-                    nid = nearer ? cid : nid;
-                    const float f = force_fast_cs(fc, d * inv_s2);
-                    const float coef = (act && d > 0.f) ? f * __builtin_amdgcn_rsqf(d) : 0.f;
-                    Fx = __builtin_fmaf(coef, dx, Fx); // (this path's sum order differs from the reference's anyway)
-                    Fy = __builtin_fmaf(coef, dy, Fy);
-                    Fz = __builtin_fmaf(coef, dz, Fz);
-                    coincident = coincident || (act && !(d > 0.f));
-                }
-            }
+            };
+            if (8 * S > 64) word_pass(m2, 8 * S - 96);
+            if (8 * S > 32) word_pass(m1, 8 * S - 64);
+            word_pass(m0, 8 * S - 32);
+            const int n_lim = n_oth + 1;
             CS_STAMP(3) // ring pass
             // not provable here: support wider than the certified radius, ring overflow, more than k points
             // inside the support (then some of them are NOT among the k nearest), r = 0 (substitute direction)
