@@ -525,6 +525,15 @@ __global__ __launch_bounds__(kCsThreads, 4) void cs2_kernel(SearchArgs<float> a,
 #undef CS_TEST
             }
             S = __builtin_amdgcn_readfirstlane(S);
+            // the query's own bit: it is always set (d = 0), and skipping it here (src/repel.jl:271 skips self by index)
+            // saves a trip of the force pass for the lanes with the most hits
+            if (!(cs_fail || giveup)) {
+                const uint32_t bit = (uint32_t)(8 * S - 1) - ((qoff - pa0) >> 4);
+                const uint32_t one = 1u << (bit & 31u);
+                m0 &= bit < 32u ? ~one : ~0u;
+                m1 &= (bit >= 32u && bit < 64u) ? ~one : ~0u;
+                m2 &= bit >= 64u ? ~one : ~0u;
+            }
             CS_STAMP(2) // scan
 
             // ---- force pass: canonical d2 of every hit, exact cut, force sum (src/repel.jl:270-280) ----
@@ -576,9 +585,31 @@ __global__ __launch_bounds__(kCsThreads, 4) void cs2_kernel(SearchArgs<float> a,
                     visit(c2);
                 }
             };
-            if (8 * S > 64) word_pass(m2, 8 * S - 96);
-            if (8 * S > 32) word_pass(m1, 8 * S - 64);
-            word_pass(m0, 8 * S - 32);
+            if (8 * S > 64) word_pass(m2, 8 * S - 96); // runs beyond 64 slots (one wave-round in ~15): their first slots
+            {
+                // the two low words in ONE loop: a lane takes its hits from m1 until that is empty, then from m0 — the trip count
+                // is the largest hit count of the wave, not the sum of the two words' largest counts (6.8 -> ~5 trips per round)
+                const uint32_t base1 = pa0 + (uint32_t)((8 * S - 64) * 16), base0 = pa0 + (uint32_t)((8 * S - 32) * 16);
+                auto take = [&](uint32_t& off) {
+                    const bool hi = m1 != 0u;
+                    const uint32_t cur = hi ? m1 : m0;
+                    uint32_t l;
+                    asm("v_ffbh_u32 %0, %1" : "=v"(l) : "v"(cur));
+                    off = cur != 0u ? (hi ? base1 : base0) + (l << 4) : qoff;
+                    const uint32_t rest = cur & ~(0x80000000u >> (l & 31u));
+                    m1 = hi ? rest : m1;
+                    m0 = hi ? m0 : rest;
+                };
+                while (__any((m1 | m0) != 0u)) {
+                    if (WTP_DIAG) dt[13] += 1; // force-pass trips (per wave)
+                    uint32_t o1, o2;
+                    take(o1);
+                    take(o2);
+                    const float4 c1 = cs_pt(smem_raw, o1), c2 = cs_pt(smem_raw, o2);
+                    visit(c1);
+                    visit(c2);
+                }
+            }
             const int n_lim = n_oth + 1;
             CS_STAMP(3) // ring pass
             // not provable here: support wider than the certified radius, ring overflow, more than k points
