@@ -366,21 +366,38 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
 // lane ranks its entry by the canonical (d2, index) order with a broadcast compare loop and
 // writes it to its final place in the CSR row.  Rows longer than the LDS list are handed to the
 // serial kernel (wtp_generic.hip) through the fb2 list.
+// Round 3: (a) the nine x-rows of the block are fetched TOGETHER — bounds by lanes 0..8 in one round trip, then one load
+// per row in flight at once — instead of nine dependent (bounds -> points) chains per query; (b) a lean per-wave list
+// (8 or 12 bytes per entry, 256 entries: eight workgroups per CU instead of two); (c) fp32 rows are ranked on ONE 64-bit
+// key per entry, (d2 bits << 32 | id) — monotone in (d2, id) because d2 >= 0 — two keys per LDS read, every lane ranking
+// all the entries it owns in the same pass.  Graded 1 M-point cloud, rows of ~65: fill 3.0 -> see DESIGN.md §4.
+constexpr int kRadCap = 512;  // entries a wave ranks in LDS; longer rows: the serial kernel
+constexpr int kRadOwn = kRadCap / 64;
+template <typename T> struct RadSmem;
+template <> struct RadSmem<float> {
+    unsigned long long key[kRadCap + 2];
+};
+template <> struct RadSmem<double> {
+    double d2[kRadCap + 2];
+    int32_t id[kRadCap + 2];
+};
+
 template <typename T, bool FILL>
 __global__ __launch_bounds__(kThreads) void wave_radius_kernel(SearchArgs<T> a, T r, int32_t* __restrict__ counts,
                                                                const int64_t* __restrict__ offsets,
                                                                int32_t* __restrict__ idx_out,
                                                                const int32_t* __restrict__ list,
                                                                const int32_t* __restrict__ list_count) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ RadSmem<T> sm_all[FILL ? kWaves : 1];
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    WaveSmem<T>* sm = reinterpret_cast<WaveSmem<T>*>(smem_raw) + wave;
+    RadSmem<T>* sm = &sm_all[FILL ? wave : 0];
     const Grid<T> g = *a.grid;
     const T r2 = r * r; // inclusive, compared as d2 <= r*r
     const int wave_global = blockIdx.x * kWaves + wave;
     const int wave_stride = gridDim.x * kWaves;
     const int nq = list ? *list_count : a.n; // list: the queries the brick kernel handed back
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     for (int qi = wave_global; qi < nq; qi += wave_stride) {
         const int slot = list ? list[qi] : qi;
         const Pt<T> q = a.snap[slot];
@@ -389,38 +406,64 @@ __global__ __launch_bounds__(kThreads) void wave_radius_kernel(SearchArgs<T> a, 
         const int z0 = cz - 1 < 0 ? 0 : cz - 1, z1 = cz + 1 > g.n[2] - 1 ? g.n[2] - 1 : cz + 1;
         const int y0 = cy - 1 < 0 ? 0 : cy - 1, y1 = cy + 1 > g.n[1] - 1 ? g.n[1] - 1 : cy + 1;
         const int x0 = cx - 1 < 0 ? 0 : cx - 1, x1 = cx + 1 > g.n[0] - 1 ? g.n[0] - 1 : cx + 1;
+        // lanes 0 .. 8: the bounds of one x-row each (absent rows: empty)
+        const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+        int my_ps = 0, my_pe = 0;
+        if (lane < nrows) {
+            const int row = ((z0 + lane / ny) * g.n[1] + (y0 + lane % ny)) * g.n[0];
+            my_ps = a.cell_start[row + x0];
+            my_pe = a.cell_start[row + x1 + 1];
+        }
+        int ps[9], len[9];
+        Pt<T> c[9];
+#pragma unroll
+        for (int rr = 0; rr < 9; ++rr) {
+            ps[rr] = __builtin_amdgcn_readlane(my_ps, rr);
+            len[rr] = __builtin_amdgcn_readlane(my_pe, rr) - ps[rr];
+        }
+#pragma unroll
+        for (int rr = 0; rr < 9; ++rr) // the first 64 points of every row: nine loads in flight
+            if (lane < len[rr]) c[rr] = a.snap[ps[rr] + lane];
         int m = 0;
-        for (int z = z0; z <= z1; ++z)
-            for (int y = y0; y <= y1; ++y) {
-                const int row = (z * g.n[1] + y) * g.n[0];
-                const int ps = a.cell_start[row + x0], pe = a.cell_start[row + x1 + 1];
-                for (int p0 = ps; p0 < pe; p0 += 64) {
-                    const int p = p0 + lane;
-                    bool take = false;
-                    T d = 0;
-                    int32_t cid = 0;
-                    if (p < pe) {
-                        const Pt<T> c = a.snap[p];
-                        cid = w_to_id(c.w);
-                        d = dist2<T>(q.x, q.y, q.z, c.x, c.y, c.z);
-                        take = (d <= r2) && (cid != id); // filter(!=(i), n), src/topology.jl:96
+        auto visit = [&](const Pt<T>& cc, bool on) {
+            bool take = false;
+            T d = 0;
+            int32_t cid = 0;
+            if (on) {
+                cid = w_to_id(cc.w);
+                d = dist2<T>(q.x, q.y, q.z, cc.x, cc.y, cc.z);
+                take = (d <= r2) && (cid != id); // filter(!=(i), n), src/topology.jl:96
+            }
+            const unsigned long long mask = __ballot(take);
+            if (FILL) {
+                const int pos = m + __popcll(mask & below);
+                if (take && pos < kRadCap) {
+                    if constexpr (sizeof(T) == 4) {
+                        sm->key[pos] = ((unsigned long long)__builtin_bit_cast(uint32_t, (float)d) << 32) | (uint32_t)cid;
+                    } else {
+                        reinterpret_cast<RadSmem<double>*>(sm)->d2[pos] = (double)d;
+                        reinterpret_cast<RadSmem<double>*>(sm)->id[pos] = cid;
                     }
-                    const unsigned long long mask = __ballot(take);
-                    if (FILL) {
-                        const int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
-                        if (take && pos < kCap) {
-                            sm->d2[pos] = d;
-                            sm->id[pos] = cid;
-                        }
-                    }
-                    m += __popcll(mask);
                 }
             }
+            m += __popcll(mask);
+        };
+#pragma unroll
+        for (int rr = 0; rr < 9; ++rr) {
+            if (len[rr] <= 0) continue; // (wave-uniform)
+            visit(c[rr], lane < len[rr]);
+            for (int p0 = 64; p0 < len[rr]; p0 += 64) { // rows beyond 64 points (dense clusters)
+                const bool on = p0 + lane < len[rr];
+                Pt<T> cc{};
+                if (on) cc = a.snap[ps[rr] + p0 + lane];
+                visit(cc, on);
+            }
+        }
         if (!FILL) {
             if (lane == 0) counts[id] = m;
             continue;
         }
-        if (m > kCap) { // row longer than the LDS list: serial kernel
+        if (m > kRadCap) { // row longer than the LDS list: serial kernel
             if (lane == 0) {
                 const int pos = atomicAdd(a.fb2_count, 1);
                 a.fb2_list[pos] = slot;
@@ -430,12 +473,37 @@ __global__ __launch_bounds__(kThreads) void wave_radius_kernel(SearchArgs<T> a, 
         __builtin_amdgcn_wave_barrier();
         const int64_t base = offsets[id];
         const int64_t cap = offsets[id + 1] - base;
-        for (int i = lane; i < m; i += 64) {
-            const T md = sm->d2[i];
-            const int32_t mi = sm->id[i];
-            int rank = 0;
-            for (int j = 0; j < m; ++j) rank += lex_lt(sm->d2[j], sm->id[j], md, mi) ? 1 : 0;
-            if (rank < cap) idx_out[base + rank] = mi;
+        if constexpr (sizeof(T) == 4) {
+            // every lane ranks the (up to four) entries it owns against all m keys, two keys per LDS read
+            if (lane == 0) sm->key[m] = ~0ull; // an odd m reads one key past the end
+            __builtin_amdgcn_wave_barrier();
+            unsigned long long mine[kRadOwn];
+            int rank[kRadOwn];
+#pragma unroll
+            for (int o = 0; o < kRadOwn; ++o) {
+                mine[o] = lane + 64 * o < m ? sm->key[lane + 64 * o] : 0ull;
+                rank[o] = 0;
+            }
+            const int owned = (m + 63) / 64; // (wave-uniform)
+            for (int j = 0; j < m; j += 2) {
+                const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(&sm->key[j]);
+#pragma unroll
+                for (int o = 0; o < kRadOwn; ++o) {
+                    if (o < owned) rank[o] += (kk.x < mine[o] ? 1 : 0) + (kk.y < mine[o] ? 1 : 0);
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < kRadOwn; ++o)
+                if (lane + 64 * o < m && rank[o] < cap) idx_out[base + rank[o]] = (int32_t)(uint32_t)mine[o];
+        } else {
+            const RadSmem<double>* sd = reinterpret_cast<const RadSmem<double>*>(sm);
+            for (int i = lane; i < m; i += 64) {
+                const T md = (T)sd->d2[i];
+                const int32_t mi = sd->id[i];
+                int rank = 0;
+                for (int j = 0; j < m; ++j) rank += lex_lt((T)sd->d2[j], sd->id[j], md, mi) ? 1 : 0;
+                if (rank < cap) idx_out[base + rank] = mi;
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -457,10 +525,9 @@ int launch_wave_radius_count(wtp_ctx* ctx, SearchArgs<T>& a, T r, int32_t* d_cou
 template <typename T>
 int launch_wave_radius_fill(wtp_ctx* ctx, SearchArgs<T>& a, T r, const int64_t* d_offsets, int32_t* d_idx,
                             const int32_t* list, const int32_t* list_count) {
-    (void)launch_occupancy_of(ctx, (const void*)wave_radius_kernel<T, true>, kThreads, wave_smem<T>());
     int64_t want = ((int64_t)a.n / (list ? 16 : 1) + kWaves - 1) / kWaves;
     int nb = (int)(want > 16384 ? 16384 : (want < 64 ? 64 : want));
-    hipLaunchKernelGGL((wave_radius_kernel<T, true>), dim3(nb), dim3(kThreads), wave_smem<T>(), ctx->stream, a, r,
+    hipLaunchKernelGGL((wave_radius_kernel<T, true>), dim3(nb), dim3(kThreads), 0, ctx->stream, a, r,
                        (int32_t*)nullptr, d_offsets, d_idx, list, list_count);
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;
