@@ -236,4 +236,47 @@ function rebuild_topology!(topo::WhatsThePoint.RadiusTopology, pts)
     return nothing
 end
 
+
+# ---- multi-GPU, round 3: the whole sharded iteration behind the ABI (include/wtp.h: wtp_block_*) -------------------------
+# One call per iteration replaces the body of `_relax!`'s loop (src/repel.jl:243-334) on a cloud cut into the boxes of an
+# orthtree partition; INTEGRATION.md "Driving the multi-GPU iteration from Julia".  Written blind like the rest of this file.
+struct BlockDesc
+    rank::Int32; nranks::Int32; boxes::Ptr{Float64}; ghost_width::Float64; margin::Float64
+end
+mutable struct BlockInfo
+    n_owned::Int64; n_ghost::Int64; n_sent_rows::Int64; n_recv_rows::Int64; n_emigrated::Int64; n_immigrated::Int64
+    n_peers::Int32; widened::Int32; host_syncs::Int32; redone::Int32; ghost_width::Float64
+    BlockInfo() = new()
+end
+block_grid(nranks::Int) = (p = Vector{Cint}(undef, 3); ccall((:wtp_block_grid, lib), Cint, (Cint, Ptr{Cint}), nranks, p); Tuple(Int.(p)))
+block_morton_rank(ix, iy, iz, p) = Int(ccall((:wtp_block_morton_rank, lib), Cint, (Cint, Cint, Cint, Ptr{Cint}), ix, iy, iz, Cint[p...]))
+
+# boxes: 6 x nranks Float64 ({lo xyz, hi xyz} per rank, identical on every rank); d_owned / d_gid: device pointers
+function block_open(rank::Int, boxes::Matrix{Float64}, d_owned::Ptr{Cvoid}, d_gid::Ptr{Int64}, n_owned::Int, sd::SpacingDesc,
+                    fd::ForceDesc, k::Int, alpha_lo, alpha_max; ghost_width::Float64, margin::Float64 = -1.0)
+    GC.@preserve boxes begin
+        desc = BlockDesc(Int32(rank), Int32(size(boxes, 2)), pointer(boxes), ghost_width, margin)
+        check(context(), ccall((:wtp_block_open, lib), Cint,
+              (Ptr{Cvoid}, Ref{BlockDesc}, Ptr{Cvoid}, Ptr{Int64}, Int64, Ref{SpacingDesc}, Ref{ForceDesc}, Cint, Cdouble, Cdouble),
+              context(), desc, d_owned, d_gid, n_owned, sd, fd, k, alpha_lo, alpha_max))
+    end
+end
+function block_step!(st::StepStats, info::BlockInfo)           # st: the GLOBAL statistics, the same on every rank
+    check(context(), ccall((:wtp_block_step, lib), Cint, (Ptr{Cvoid}, Ref{StepStats}, Ref{BlockInfo}), context(), st, info))
+    st
+end
+function block_run_until(max_iters::Int; tol = 1e-6, stall_after = 50, cv_target = 0.0)   # src/repel.jl:305-334 on the global numbers
+    conv = Vector{Float64}(undef, max(max_iters, 1)); nd = Ref{Cint}(0); why = Ref{Cint}(0); st = StepStats()
+    check(context(), ccall((:wtp_block_run_until, lib), Cint,
+          (Ptr{Cvoid}, Cint, Cdouble, Cint, Cdouble, Ptr{Float64}, Ref{Cint}, Ref{Cint}, Ref{StepStats}),
+          context(), max_iters, tol, stall_after, cv_target, conv, nd, why, st))
+    conv[1:nd[]], Int(why[]), st
+end
+function block_get(d_xyz::Ptr{Cvoid}, d_gid::Ptr{Int64}, cap::Int)
+    n = Ref{Int64}(0)
+    check(context(), ccall((:wtp_block_get, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int64}, Int64, Ref{Int64}), context(), d_xyz, d_gid, cap, n))
+    Int(n[])
+end
+block_close() = check(context(), ccall((:wtp_block_close, lib), Cint, (Ptr{Cvoid},), context()))
+
 end # module
