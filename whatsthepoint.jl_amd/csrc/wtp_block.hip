@@ -42,6 +42,7 @@ struct BlkGeom {
     float in_lo[kBlkMaxPeers][3], in_hi[kBlkMaxPeers][3]; // peer box widened by w + margin: who needs a point as a ghost
     float bx_lo[kBlkMaxPeers][3], bx_hi[kBlkMaxPeers][3]; // peer box itself: who owns a point
     float out_lo[3], out_hi[3];                           // own box widened by margin: beyond it a point changes owner
+    float deep_lo[3], deep_hi[3];                         // own box shrunk by w + margin: a point in there is nobody's ghost
 };
 
 // columns of the per-span count table: [0, np) ghost rows per peer, [np, 2 np) migrants per peer, 2 np points that stay
@@ -111,7 +112,8 @@ __global__ __launch_bounds__(64 * kBlkWaves) void blk_classify_kernel(const floa
         if (i < n) {
             const float4 p = P[i];
             movable = w_to_id(p.w) >= n_fixed;
-            if (movable) {
+            // (most points lie deeper inside the box than any peer's layer reaches: six compares settle them)
+            if (movable && !blk_inside(p, g.deep_lo, g.deep_hi)) {
                 const bool leaves = !blk_inside(p, g.out_lo, g.out_hi);
                 int owner = -1;
                 for (int q = 0; q < np; ++q) {
@@ -350,6 +352,9 @@ static int blk_geometry(wtp_ctx* ctx, BlockState* b) {
     for (int ax = 0; ax < 3; ++ax) {
         g.out_lo[ax] = (float)(mine[ax] - b->margin);
         g.out_hi[ax] = (float)(mine[3 + ax] + b->margin);
+        // every peer's box lies outside mine, so its layer reaches at most w_eff into my box (one float ulp of slack)
+        g.deep_lo[ax] = std::nextafter((float)(mine[ax] + w_eff), std::numeric_limits<float>::infinity());
+        g.deep_hi[ax] = std::nextafter((float)(mine[3 + ax] - w_eff), -std::numeric_limits<float>::infinity());
     }
     const size_t np = b->peers.size();
     b->send_cnt.assign(np, 0);
