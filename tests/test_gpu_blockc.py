@@ -92,6 +92,9 @@ def test_octants_with_the_product_engine_match_single_domain(wtp):
     assert sum(h["n_emigrated"] for hh in hists for h in hh) > 0, "margin 0: somebody crossed a face"
     assert sum(h["n_emigrated"] for hh in hists for h in hh) == sum(h["n_immigrated"] for hh in hists for h in hh)
     assert all(h["n_uncovered"] == 0 for hh in hists for h in hh)
+    # host synchronisations per iteration: the statistics gather (the one a RCCL run has) + the two around the
+    # loopback exchange's staging through host memory — migration, ghosts and classification add none
+    assert all(h["host_syncs"] == 3 for hh in hists for h in hh[1:]), [[h["host_syncs"] for h in hh] for hh in hists]
     # every rank saw the same global statistics
     for i in range(iters):
         assert len({hh[i]["max_force"] for hh in hists}) == 1 and len({hh[i]["sum_u"] for hh in hists}) == 1

@@ -1904,7 +1904,8 @@ static int flush_pending(wtp_ctx* ctx) {
     return WTP_OK;
 }
 
-WTP_API int wtp_relax_set_fixed_dev(wtp_ctx* ctx, const void* d_fixed4, int64_t n_fixed_new) {
+// (keep_alive: the caller's array stays valid until the copy has run in stream order — the block driver's own pool)
+int wtp::relax_set_fixed_dev_impl(wtp_ctx* ctx, const void* d_fixed4, int64_t n_fixed_new, bool keep_alive) {
     if (!ctx) return WTP_ERR_ARG;
     RelaxState& r = ctx->relax;
     if (!r.active) return fail(ctx, WTP_ERR_STATE, "wtp_relax_set_fixed_dev before wtp_relax_init");
@@ -1982,7 +1983,11 @@ WTP_API int wtp_relax_set_fixed_dev(wtp_ctx* ctx, const void* d_fixed4, int64_t 
     r.can_revert = false;
     r.have_point_data = false;
     // the caller's array must outlive the copy: on a lent stream that is stream order, else wait
-    return ctx->stream == ctx->own_stream ? sync(ctx) : WTP_OK;
+    return (ctx->stream == ctx->own_stream && !keep_alive) ? sync(ctx) : WTP_OK;
+}
+
+WTP_API int wtp_relax_set_fixed_dev(wtp_ctx* ctx, const void* d_fixed4, int64_t n_fixed_new) {
+    return relax_set_fixed_dev_impl(ctx, d_fixed4, n_fixed_new, false);
 }
 
 WTP_API int wtp_relax_set_coverage(wtp_ctx* ctx, int axis, double lo, double hi) {

@@ -750,7 +750,7 @@ static int blk_exchange_and_apply(wtp_ctx* ctx, BlockState* b) {
     b->n_ghost = n_pool;
     WTP_HIP(ctx, hipGetLastError());
     if (n_pool == 0 && r.n_fixed == 0) return WTP_OK; // no ghosts before, none now: the session is untouched (one rank: it IS the plain session)
-    return wtp_relax_set_fixed_dev(ctx, n_pool ? b->pool.p : nullptr, n_pool);
+    return relax_set_fixed_dev_impl(ctx, n_pool ? b->pool.p : nullptr, n_pool, true); // (the pool is ours: no wait for the copy)
 }
 
 WTP_API int wtp_block_step(wtp_ctx* ctx, wtp_step_stats* stats, wtp_block_info* info) {

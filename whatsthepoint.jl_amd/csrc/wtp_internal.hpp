@@ -423,6 +423,7 @@ template <typename T> int launch_append_fixed(wtp_ctx* ctx, const Pt<T>* d_src, 
 int relax_step_enqueue(wtp_ctx* ctx, int rebuild, wtp_step_stats* d_slot); // one sweep, statistics into a device slot, no synchronisation
 int relax_swap_begin(wtp_ctx* ctx, int64_t n_move_new, void** d_buf_out);  // a free point buffer for a replaced movable set ...
 int relax_swap_commit(wtp_ctx* ctx, int64_t n_move_new);                   // ... which becomes the session's P (no fixed head, tuning kept)
+int relax_set_fixed_dev_impl(wtp_ctx* ctx, const void* d_fixed4, int64_t n_fixed_new, bool keep_alive);
 void block_destroy(wtp_ctx* ctx);                                          // frees ctx->block (wtp_destroy)
 template <typename T>
 int launch_refix(wtp_ctx* ctx, const Pt<T>* in, int64_t n_old, int64_t n_fixed_old, int64_t n_fixed_new,
