@@ -1136,14 +1136,20 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
             }
             r.grid_tuned = true;
             r.tuned_fixed = r.n_fixed;
+            r.grid_fixed = r.n_fixed;
             r.grid_age = 0;
         } else {
             // The bounding box moves by at most a spacing per sweep: it is recomputed every few rebuilds only
             // (and always after a point was placed by hand, a fixed head was swapped, or with a clipped box).
-            const bool reuse = r.grid_age < ctx->grid_reuse_max && !r.moved_by_hand && !ctx->hash_view.active &&
-                               !ctx->box_active;
+            // A block session swaps its ghost head every iteration; the layer keeps its place and, nearly, its size, so the
+            // box of the last full pass still fits (what sticks out is clamped into edge cells: exact, as for a moved point).
+            const bool head_ok = !ctx->hash_view.active ||
+                                 (r.shard_grid_reuse && r.grid_fixed > 0 &&
+                                  std::llabs((long long)(r.n_fixed - r.grid_fixed)) * 10 <= (long long)r.grid_fixed + 640);
+            const bool reuse = r.grid_age < ctx->grid_reuse_max && !r.moved_by_hand && head_ok && !ctx->box_active;
             ctx->reuse_grid = reuse;
             r.grid_age = reuse ? r.grid_age + 1 : 0;
+            if (!reuse) r.grid_fixed = r.n_fixed;
             rc = build_hash<T>(ctx, (const Pt<T>*)ctx->pts[r.bufP].p, (Pt<T>*)ctx->pts[t].p, r.n, r.dim, r.k, 0.0, rho_cs,
                                min_cell, r.cell_scale);
             ctx->reuse_grid = false;

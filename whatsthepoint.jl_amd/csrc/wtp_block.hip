@@ -620,6 +620,7 @@ WTP_API int wtp_block_open(wtp_ctx* ctx, const wtp_block_desc* desc, const void*
     WTP_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
     if ((rc = wtp_relax_init_dev(ctx, d_owned_xyz, n_owned, 0, 3, WTP_F32, spacing, force, k, alpha_lo, alpha_max))) return rc;
+    ctx->relax.shard_grid_reuse = true;
     b->rank = desc->rank;
     b->nranks = desc->nranks;
     b->boxes.assign(desc->boxes, desc->boxes + (size_t)desc->nranks * 6);

@@ -184,6 +184,8 @@ struct RelaxState {
     int64_t shard_extra = 0; // extra capacity of the point buffers once the fixed head gets replaced
     int64_t aux_off = 0;     // device-evaluated spacing laws: sp_hint / sp_cert are stored at [id - aux_off] (a swapped fixed head shifts the movable ids, not the entries)
     int swap_target = -1;    // relax_swap_begin .. relax_swap_commit (wtp_block.hip: migration)
+    bool shard_grid_reuse = false; // block sessions: the grid is kept across a swapped ghost head (points outside it pile into edge cells, which every search treats as unbounded outward)
+    int64_t grid_fixed = -1;       // fixed points the current grid's bounding box was computed with
     bool wall_active = false; // octree method: _constrain_octree runs after every sweep (wtp_relax_set_wall)
     double wall_offset = 0;   // inward nudge of a projected boundary point (src/repel.jl:143)
     int64_t wall_nm = 0;      // movable points the wall arrays are sized for
