@@ -105,12 +105,20 @@ __global__ __launch_bounds__(64 * kBlkWaves) void blk_classify_kernel(const floa
     const int np = g.np, ncol = blk_cols(np);
     int cnt = 0; // lane c holds the span's count of column c
     int n_lost = 0;
+    // the span's sixteen loads in flight together (in a loop with the ballots between them they were sixteen round trips)
+    float4 pp[kBlkPasses];
+#pragma unroll
+    for (int pass = 0; pass < kBlkPasses; ++pass) {
+        const int64_t i = first + (int64_t)pass * 64 + lane;
+        pp[pass] = P[i < n ? i : n - 1];
+    }
+#pragma unroll
     for (int pass = 0; pass < kBlkPasses; ++pass) {
         const int64_t i = first + (int64_t)pass * 64 + lane;
         uint32_t flag = 0;
         bool movable = false;
         if (i < n) {
-            const float4 p = P[i];
+            const float4 p = pp[pass];
             movable = w_to_id(p.w) >= n_fixed;
             // (most points lie deeper inside the box than any peer's layer reaches: six compares settle them)
             if (movable && !blk_inside(p, g.deep_lo, g.deep_hi)) {
@@ -209,9 +217,16 @@ __global__ __launch_bounds__(64 * kBlkWaves) void blk_fill_kernel(const float4* 
         run = base + span_off[span * ncol + lane];
     }
     const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    uint32_t ff[kBlkPasses]; // the span's flags, all loads in flight together
+#pragma unroll
     for (int pass = 0; pass < kBlkPasses; ++pass) {
         const int64_t i = first + (int64_t)pass * 64 + lane;
-        const uint32_t flag = i < n ? flags[i] : 0u;
+        ff[pass] = i < n ? flags[i] : 0u;
+    }
+#pragma unroll
+    for (int pass = 0; pass < kBlkPasses; ++pass) {
+        const int64_t i = first + (int64_t)pass * 64 + lane;
+        const uint32_t flag = ff[pass];
         if (__ballot(flag != 0) == 0ull) continue;
         float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
         if (flag) p = P[i];
