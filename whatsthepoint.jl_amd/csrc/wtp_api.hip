@@ -269,6 +269,45 @@ static int build_hash_tuned(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n
 }
 
 // ---- topology -----------------------------------------------------------------------------------
+// Brick geometry of wtp_ksel.hip from the measured grid: the brick length along x that puts ~224 queries on the 256
+// lanes (four own cells per column; the denser of the box average and the occupancy the points see), and the LDS
+// point area for its halo of 36 cells per column plus five standard deviations.
+static void ksel_geometry(wtp_ctx* ctx, double n, double ncells, int n0, double rho_eff, int* bx_out, int* hcap_out) {
+    double rho_cell = ncells > 0 ? n / ncells : 1.0;
+    if (rho_eff - 1.0 > rho_cell) rho_cell = rho_eff - 1.0;
+    if (rho_cell < 0.05) rho_cell = 0.05;
+    // Bricks of equal length along x: among the splits of the n0 columns, the one with the lowest expected cost per
+    // query — a brick costs one round of the 256 lanes, two when its Q own points (Poisson) exceed them
+    int bx = ksel_max_bx();
+    double best = 1e300;
+    for (int nbx = 1; nbx <= n0; ++nbx) {
+        const int b = (n0 + nbx - 1) / nbx;
+        if (b > ksel_max_bx()) continue;
+        const double q = 4.0 * rho_cell * b;
+        const double p2 = 0.5 * std::erfc((256.0 - q) / std::sqrt(2.0 * (q > 1 ? q : 1)));
+        const double cost = (1.0 + p2 + (q > 512.0 ? 100.0 : 0.0)) / q;
+        if (cost < best) {
+            best = cost;
+            bx = b;
+        }
+        if (b < 8) break;
+    }
+    bx = bx < 8 ? (n0 < 8 ? (n0 > 0 ? n0 : 1) : 8) : bx;
+    const double halo = 36.0 * (bx + 4) * rho_cell;
+    int hc = (int)(halo + 5.0 * std::sqrt(halo)) + 32;
+    hc = (hc + 63) / 64 * 64;
+    *bx_out = bx;
+    *hcap_out = hc < 512 ? 512 : (hc > 3072 ? 3072 : hc);
+    if (getenv("WTP_DEBUG"))
+        fprintf(stderr, "[wtp] ksel geometry: rho_cell %.3f (box average %.3f), %d columns -> bricks of %d, LDS point area %d\n",
+                rho_cell, ncells > 0 ? n / ncells : 0.0, n0, *bx_out, *hcap_out);
+}
+// points the first filter ball is expected to hold: k + self plus the same number of standard deviations as
+// cap_ksel leaves at 22
+static double ksel_cap_count(const wtp_ctx* ctx, int kq) {
+    return (double)kq + (ctx->cap_ksel - 22.0) / std::sqrt(22.0) * std::sqrt((double)kq);
+}
+
 template <typename T>
 static int knn_dev_t(wtp_ctx* ctx, const T* d_xyz, int64_t n, int dim, int k, int include_self,
                      int32_t* d_idx, T* d_dist) {
@@ -288,17 +327,22 @@ static int knn_dev_t(wtp_ctx* ctx, const T* d_xyz, int64_t n, int dim, int k, in
     // The measured cell scale of the last topology call is reused for a cloud of the same size (the
     // usual case: rebuild_topology! on the same points); it only affects speed, never the result.
     const int kq = include_self ? k : k + 1;
+    // fp32 3-D clouds with k + self <= 22 (the reference's k = 21 among them): the x-slowest layout of wtp_ksel.hip —
+    // cells of ~1.2 points, the k nearest inside the 5 x 5 x 5 block around the query's cell
+    const bool ksel = sizeof(T) == 4 && dim == 3 && ctx->ksel && !ctx->force_generic && kq <= ksel_kmax() && n >= 4096;
+    const double rho_direct = ksel ? ctx->rho_ksel * (double)kq / 22.0 : 0.0;
     ctx->topology_build = true;
-    if (ctx->knn_tune_n == n && ctx->knn_tune_dim == dim && ctx->knn_tune_k == kq && !ctx->knn_tune_boxed) {
+    if (ctx->knn_tune_n == n && ctx->knn_tune_dim == dim && ctx->knn_tune_k == kq && !ctx->knn_tune_boxed &&
+        ctx->knn_tune_ksel == (int)ksel) {
         ctx->box_active = false;
-        if ((rc = build_hash<T>(ctx, raw, sorted, n, dim, kq, 0.0, 0.0, 0.0, ctx->knn_tune_scale))) {
+        if ((rc = build_hash<T>(ctx, raw, sorted, n, dim, kq, 0.0, rho_direct, 0.0, ctx->knn_tune_scale))) {
             ctx->topology_build = false;
             return rc;
         }
     } else {
         double scale = 1.0, rho_eff = 0;
         Grid<T> hg;
-        if ((rc = build_hash_tuned<T>(ctx, raw, sorted, n, dim, kq, 0.0, 0.0, 0.0, &scale, &rho_eff, &hg))) {
+        if ((rc = build_hash_tuned<T>(ctx, raw, sorted, n, dim, kq, 0.0, rho_direct, 0.0, &scale, &rho_eff, &hg))) {
             ctx->topology_build = false;
             return rc;
         }
@@ -307,6 +351,8 @@ static int knn_dev_t(wtp_ctx* ctx, const T* d_xyz, int64_t n, int dim, int k, in
         ctx->knn_tune_k = kq;
         ctx->knn_tune_scale = scale;
         ctx->knn_tune_boxed = ctx->box_active; // a clipped box belongs to this very cloud: never reuse it
+        ctx->knn_tune_ksel = (int)ksel;
+        if (ksel) ksel_geometry(ctx, (double)n, (double)hg.ncells, hg.n[0], rho_eff, &ctx->knn_tune_bx, &ctx->knn_tune_hcap);
     }
     ctx->topology_build = false;
     span_end(ctx, sp);
@@ -326,6 +372,11 @@ static int knn_dev_t(wtp_ctx* ctx, const T* d_xyz, int64_t n, int dim, int k, in
     a.fb2_count = (int32_t*)ctx->fb2_count.p;
     if ((rc = ensure(ctx, ctx->diag, 128))) return rc;
     a.diag = (unsigned long long*)ctx->diag.p; // (written by -DWTP_DIAG builds only)
+    if (ksel) {
+        a.ksel_bx = ctx->knn_tune_bx;
+        a.brick_hcap = ctx->knn_tune_hcap;
+        a.cap_count = (float)ksel_cap_count(ctx, kq);
+    }
     sp = span_begin(ctx, 1);
     rc = launch_topology<T>(ctx, a);
     span_end(ctx, sp);
@@ -498,6 +549,9 @@ WTP_API int wtp_create(const int* device_ordinals, int n_dev, wtp_ctx** out) {
     if (const char* e = getenv("WTP_FORCE_GENERIC")) ctx->force_generic = atoi(e);
     if (const char* e = getenv("WTP_FULL_SELECT")) ctx->full_select = atoi(e);
     if (const char* e = getenv("WTP_CS2")) ctx->cs2 = atoi(e);
+    if (const char* e = getenv("WTP_KSEL")) ctx->ksel = atoi(e);
+    if (const char* e = getenv("WTP_RHO_KSEL")) ctx->rho_ksel = atof(e) > 0 ? atof(e) : ctx->rho_ksel;
+    if (const char* e = getenv("WTP_CAP_KSEL")) ctx->cap_ksel = atof(e) > 0 ? atof(e) : ctx->cap_ksel;
     if (const char* e = getenv("WTP_RHO_CS")) ctx->rho_cs2 = atof(e) >= 1.0 ? atof(e) : ctx->rho_cs2;
     if (const char* e = getenv("WTP_STYP_SIGMA")) ctx->styp_sigma = atof(e);
     if (const char* e = getenv("WTP_TIMING")) {

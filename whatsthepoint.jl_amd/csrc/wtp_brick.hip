@@ -393,8 +393,11 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
         DIAG_STAMP(0) // brick setup + halo staging
         __builtin_amdgcn_s_setprio(1); // waves that run queries issue ahead of waves that stage (measured on the round-2 sweep: -3.5 %)
         const int Q = sm->own_pref[kOwnRows];
+        const int rot = ((brick / blk_per_group + blockIdx.x) & 3) << 6;
         for (int qb = 0; qb < Q; qb += kBrickThreads) {
-            const int q = qb + tid;
+            // the last, partial round of a brick falls on wave 0 of the round; rotating the wave order from brick to
+            // brick spreads those rounds over the four SIMDs instead of loading the first one
+            const int q = qb + ((tid + rot) & (kBrickThreads - 1));
             const bool active = q < Q;
             int r = 0;
             if (active) {
@@ -930,6 +933,12 @@ int launch_brick_radius(wtp_ctx* ctx, SearchArgs<float>& a) {
 
 template <> int launch_topology<float>(wtp_ctx* ctx, SearchArgs<float>& a) {
     if (a.k > kFastKMax - 1 || ctx->force_generic) return launch_generic_topology<float>(ctx, a, true);
+    if (a.ksel_bx > 0) { // the caller built the grid for the x-slowest layout (wtp_ksel.hip)
+        WTP_HIP(ctx, hipMemsetAsync(a.fb_count, 0, sizeof(int32_t), ctx->stream));
+        const int rk = launch_ksel_topology(ctx, a);
+        if (rk) return rk;
+        return launch_generic_topology<float>(ctx, a, false);
+    }
     a.gamma_cap = (float)ctx->gamma_cap;
     a.cap_count = (float)(4.18879 * ctx->gamma_cap * ctx->gamma_cap * ctx->gamma_cap * ctx->rho * (a.k + 1) / 22.0);
     WTP_HIP(ctx, hipMemsetAsync(a.fb_count, 0, sizeof(int32_t), ctx->stream));

@@ -135,6 +135,7 @@ template <typename T> struct SearchArgs {
     T tnn_frac;                // CS sweeps: nearest-neighbour margin of the ring, in cell edges (WTP_TNN, default 0.8)
     int32_t brick_hcap;        // LDS point capacity for the brick kernel (0 = default)
     int32_t cs2_bx;            // > 0: brick length (own cells along x) of the round-2 compact-support sweep (wtp_cs2.hip)
+    int32_t ksel_bx;           // > 0: the grid was built for the k-selection kernels of wtp_ksel.hip; largest brick length along x
     unsigned long long* diag;  // -DWTP_DIAG builds: per-phase wave-cycle sums (8 slots), else unused
 };
 
@@ -211,12 +212,16 @@ struct wtp_ctx {
     int full_select = 0;       // WTP_FULL_SELECT=1: never use the compact-support sweep
     int cs2 = 1;               // WTP_CS2=0: the round-1 compact-support sweep (brick_kernel<1,0,1>) instead of wtp_cs2.hip
     double rho_cs2 = 1.0;      // WTP_RHO_CS: target points per cell of the round-2 sweep (the support floor usually binds)
+    int ksel = 1;              // WTP_KSEL=0: the round-1 k-selection kernels (4 x 4 x 4 bricks, wtp_brick.hip) instead of wtp_ksel.hip
+    double rho_ksel = 1.2;     // WTP_RHO_KSEL: points per cell of the wtp_ksel.hip grids at k + self = 22 (scales with k)
+    double cap_ksel = 40.0;    // WTP_CAP_KSEL: points the first filter ball of wtp_ksel.hip is expected to hold at k + self = 22
     size_t cs2_smem = 0;       // launch attributes of cs2_kernel cached per context
     int cs2_occ = 0;
     // (kernel, dynamic LDS bytes) -> blocks per CU, per CONTEXT: the dynamic-LDS attribute and the occupancy are
     // properties of a kernel on one device, and several contexts (devices) may live in one process
     std::map<std::pair<const void*, size_t>, int> launch_cache;
     double styp_sigma = 0.0;   // WTP_STYP_SIGMA: typical spacing = mean + this many standard deviations (measured: > 0 only hurts)
+    int knn_tune_ksel = -1, knn_tune_bx = 0, knn_tune_hcap = 0; // wtp_ksel.hip layout in use for that cloud, its brick geometry
     int64_t knn_tune_n = -1;   // topology calls: cloud size / dim / k the cached cell scale was measured for
     int knn_tune_dim = 0, knn_tune_k = 0;
     double knn_tune_scale = 1.0;
@@ -357,6 +362,11 @@ int debug_kd_steps(unsigned long long out[2]); // -DWTP_DIAG builds: node visits
 int launch_cs_ball(wtp_ctx* ctx, SearchArgs<float>& a, int32_t* rest_list, int32_t* rest_count);
 int launch_cs2_census(wtp_ctx* ctx, int BX, unsigned int* d_out513);
 int cs2_max_bx();
+// wtp_ksel.hip: k-selection on the x-slowest layout (fp32, 3-D, k + self <= ksel_kmax())
+int launch_ksel_topology(wtp_ctx* ctx, SearchArgs<float>& a);
+int launch_ksel_sweep(wtp_ctx* ctx, SearchArgs<float>& a);
+int ksel_max_bx();
+int ksel_kmax();
 template <typename T>
 int launch_radius_count(wtp_ctx* ctx, SearchArgs<T>& a, T r, int32_t* d_counts);
 template <typename T>
