@@ -35,9 +35,10 @@ else:
     sess.run_async_free(reps, 1)
 lib.wtp_debug_diag(ctx._h, out)
 if out[15]:  # wtp_ksel.hip: eight phases, wave count in slot 15
-    names = ["cell_table", "tables_staging", "query_setup", "scan", "extraction", "keys", "network_window", "rows_force_out"]
-    tot = sum(out[i] for i in range(8)) or 1
-    print(mode, n, "ksel", {names[i]: round(out[i] / tot, 4) for i in range(8)}, "waves", out[15], "cycles/wave", tot // out[15])
+    names = ["cell_table_to_barrier", "last_barrier", "query_setup", "scan", "extraction", "keys", "network_window", "rows_force_out",
+             "wait_slowest_wave", "prefix_tables", "staging"]
+    tot = sum(out[i] for i in range(11)) or 1
+    print(mode, n, "ksel", {names[i]: round(out[i] / tot, 4) for i in range(11)}, "waves", out[15], "cycles/wave", tot // out[15])
 else:
     names = ["stage", "query_setup", "scan", "select", "prune_compact", "topo_out", "force_loop"]
     tot = sum(out[i] for i in range(7)) or 1

@@ -1133,6 +1133,12 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
         // per-wave follow-up, so the cells only cover the support: rho ~ 1
         const bool cs2 = r.cs_sweep && ctx->cs2 && sizeof(T) == 4 && r.dim == 3;
         double rho_cs = r.cs_sweep ? (cs2 ? ctx->rho_cs2 : 3.5 * (ctx->rho / 9.0)) : 0.0;
+        // every other law (and ClippedSpacingForce with WTP_FULL_SELECT=1 or over-full support cells): the sweep with the
+        // explicit k-selection — on the x-slowest layout of wtp_ksel.hip where that applies (fp32, 3-D, k <= 22)
+        const bool ksel_ok = sizeof(T) == 4 && r.dim == 3 && ctx->ksel && !ctx->force_generic && r.k >= 2 &&
+                             r.k <= ksel_kmax() && r.n >= 4096;
+        r.ksel_sweep = !r.cs_sweep && ksel_ok;
+        if (r.ksel_sweep) rho_cs = ctx->rho_ksel * (double)r.k / 22.0;
         if (r.spacing_typ <= 0) { // once per session: the spacing a typical point asks for
             r.spacing_typ = r.spacing_const;
             if (r.spacing_kind != WTP_SPACING_CONSTANT) {
@@ -1171,7 +1177,8 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
             if (r.cs_sweep && rho_eff > (cs2 ? 5.0 : 4.0 * rho_cs) && 2 * r.n_fixed < r.n) {
                 r.cs_disabled = true;
                 r.cs_sweep = false;
-                rho_cs = 0.0;
+                r.ksel_sweep = ksel_ok;
+                rho_cs = r.ksel_sweep ? ctx->rho_ksel * (double)r.k / 22.0 : 0.0;
                 min_cell = 0.0;
                 r.cell_scale = 1.0;
                 rc = build_hash_tuned<T>(ctx, (const Pt<T>*)ctx->pts[r.bufP].p, (Pt<T>*)ctx->pts[t].p, r.n, r.dim, r.k, 0.0,
@@ -1188,6 +1195,7 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
                 hc = (hc + 63) / 64 * 64;
                 r.brick_hcap = hc < 640 ? 640 : (hc > 2560 ? 2560 : hc);
             }
+            if (r.ksel_sweep) ksel_geometry(ctx, (double)r.n, (double)hg.ncells, hg.n[0], rho_eff, &r.ksel_bx, &r.ksel_hcap);
             r.grid_tuned = true;
             r.tuned_fixed = r.n_fixed;
             r.grid_fixed = r.n_fixed;
@@ -1276,8 +1284,10 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
     }
     if ((rc = ensure(ctx, ctx->diag, 128))) return rc;
     a.diag = (unsigned long long*)ctx->diag.p;
-    a.brick_hcap = r.cs_sweep ? r.brick_hcap : 0;
+    a.brick_hcap = r.cs_sweep ? r.brick_hcap : (r.ksel_sweep ? r.ksel_hcap : 0);
     a.cs2_bx = r.cs_sweep ? r.cs2_bx : 0;
+    a.ksel_bx = r.ksel_sweep ? r.ksel_bx : 0;
+    if (r.ksel_sweep) a.cap_count = (float)ksel_cap_count(ctx, r.k);
     a.tnn_frac = (T)ctx->tnn_frac;
     a.cover_axis = r.cover_axis;
     a.cover_lo = (T)r.cover_lo;

@@ -937,6 +937,7 @@ template <> int launch_topology<float>(wtp_ctx* ctx, SearchArgs<float>& a) {
         WTP_HIP(ctx, hipMemsetAsync(a.fb_count, 0, sizeof(int32_t), ctx->stream));
         const int rk = launch_ksel_topology(ctx, a);
         if (rk) return rk;
+        a.fb_r0 = 3;
         return launch_generic_topology<float>(ctx, a, false);
     }
     a.gamma_cap = (float)ctx->gamma_cap;
@@ -960,6 +961,17 @@ template <> int launch_sweep<float>(wtp_ctx* ctx, SearchArgs<float>& a, bool fre
         int rc = launch_generic_sweep<float>(ctx, a, true);
         span_end(ctx, sp);
         return rc;
+    }
+    if (a.ksel_bx > 0) { // the session built the grid for the x-slowest layout (wtp_ksel.hip); a.cap_count is the caller's
+        const int spk = span_begin(ctx, 1);
+        int rk = launch_ksel_sweep(ctx, a);
+        span_end(ctx, spk);
+        if (rk) return rk;
+        const int spk2 = span_begin(ctx, 2);
+        a.fb_r0 = 3;
+        rk = launch_generic_sweep<float>(ctx, a, false);
+        span_end(ctx, spk2);
+        return rk;
     }
     a.gamma_cap = (float)ctx->gamma_cap_sweep;
     a.cap_count = (float)(4.18879 * ctx->gamma_cap_sweep * ctx->gamma_cap_sweep * ctx->gamma_cap_sweep * ctx->rho * (a.k + 1) / 22.0);

@@ -135,6 +135,7 @@ template <typename T> struct SearchArgs {
     T tnn_frac;                // CS sweeps: nearest-neighbour margin of the ring, in cell edges (WTP_TNN, default 0.8)
     int32_t brick_hcap;        // LDS point capacity for the brick kernel (0 = default)
     int32_t cs2_bx;            // > 0: brick length (own cells along x) of the round-2 compact-support sweep (wtp_cs2.hip)
+    int32_t fb_r0;             // first block radius (cells) of the exact path for hand-backs; 0: the default (2: the 27 cells failed already)
     int32_t ksel_bx;           // > 0: the grid was built for the k-selection kernels of wtp_ksel.hip; largest brick length along x
     unsigned long long* diag;  // -DWTP_DIAG builds: per-phase wave-cycle sums (8 slots), else unused
 };
@@ -178,6 +179,8 @@ struct RelaxState {
     double spacing_typ = 0;  // mean spacing over the snapshot (floor of the compact-support cell edge)
     bool cs_sweep = false;   // compact-support sweep in use (ClippedSpacingForce)
     bool cs_disabled = false; // measured on the first rebuild: support cells would be over-full, use the k-selection sweep
+    bool ksel_sweep = false; // k-selection sweep on the x-slowest layout (wtp_ksel.hip)
+    int ksel_bx = 0, ksel_hcap = 0; // its brick length along x and LDS point area, measured with the grid
     int cs2_bx = 0;          // > 0: the round-2 compact-support sweep (wtp_cs2.hip) with bricks of this many cells along x
     int64_t tuned_fixed = 0; // fixed points the grid / brick geometry was measured with (a swapped head re-measures when it differs by > 5 % of n)
     double sp_p0 = 0, sp_p1 = 0, sp_p2 = 0; // LOGLIKE / BOUNDARY_LAYER parameters

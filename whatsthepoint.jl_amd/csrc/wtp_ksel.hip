@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kKsThreads, 2) void ksel_kernel(SearchArgs<float> a
     const int nby = (g.n[1] + 1) / 2, nbz = (g.n[2] + 1) / 2;
     const int nbricks = nbx * nby * nbz;
     Acc acc = acc_empty();
-    unsigned long long dt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long dt[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_last = WTP_DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
 
     // XCD-aware brick order (blocks sharing blockIdx % 8 share an L2): one contiguous slab of bricks each
@@ -171,6 +171,17 @@ __global__ __launch_bounds__(kKsThreads, 2) void ksel_kernel(SearchArgs<float> a
         }
     };
 
+    // the first 64 points of each of the wave's rows (longer rows: the rest at staging time)
+    auto load_points = [&](const int (&vv)[kKsRows], float4 (&pp)[kKsRows]) {
+        const int last = a.n - 1;
+#pragma unroll
+        for (int j = 0; j < kKsRows; ++j) {
+            const int gs = __builtin_amdgcn_readfirstlane(vv[j]);
+            const int len = __builtin_amdgcn_readlane(vv[j], HX) - gs;
+            const int i = gs + (lane < len ? lane : 0);
+            pp[j] = a.snap[i < last ? i : last];
+        }
+    };
     int brick = xcd * per + lane_blk;
     int v[kKsRows];
 #pragma unroll
@@ -183,12 +194,14 @@ __global__ __launch_bounds__(kKsThreads, 2) void ksel_kernel(SearchArgs<float> a
 
         __builtin_amdgcn_s_setprio(0);
         __syncthreads(); // previous brick's LDS no longer in use
+        KS_STAMP(8) // wait for the brick's slowest wave
         // ---- 1. cell table: the prefix the LDS order (hx, hz, hy) needs — points left of column hx in all rows, plus
         //         the column's cells in rows before r — is a sum of cell_start values: no scan across lanes ----------
         int cn[kKsRows], row_gs[kKsRows], row_len[kKsRows];
         float4 pv[kKsRows];
+        load_points(v, pv); // in flight while the tables are built (held across the queries of the previous brick they cost
+                            // more in spills than the wait they save: measured)
         {
-            const int last = a.n - 1;
             int vs = 0, cs = 0;
 #pragma unroll
             for (int j = 0; j < kKsRows; ++j) {
@@ -198,9 +211,6 @@ __global__ __launch_bounds__(kKsThreads, 2) void ksel_kernel(SearchArgs<float> a
                 row_len[j] = __builtin_amdgcn_readlane(v[j], HX) - row_gs[j];
                 vs += v[j];
                 cs += cn[j];
-                // the row's first 64 points: in flight while the tables are built
-                const int i = row_gs[j] + (lane < row_len[j] ? lane : 0);
-                pv[j] = a.snap[i < last ? i : last];
             }
             if (lane <= HX) {
                 sm->wsum[wave][lane] = (uint32_t)vs;
@@ -249,6 +259,7 @@ __global__ __launch_bounds__(kKsThreads, 2) void ksel_kernel(SearchArgs<float> a
             }
         }
         __syncthreads();
+        KS_STAMP(9) // prefix tables
         const bool overflow = halo_total > hcap;
         if (tid >= 2 && tid <= BX + 1) {
             const int q0 = sm->qpref[tid], q1 = sm->qpref[tid + 1];
@@ -279,6 +290,7 @@ __global__ __launch_bounds__(kKsThreads, 2) void ksel_kernel(SearchArgs<float> a
         }
         // the next brick's cell table: in flight while this brick's queries run
         if (next < b_end) load_cells(brick_pos(next), v);
+        KS_STAMP(10) // staging (waits for the rows' points)
         __syncthreads();
         KS_STAMP(1) // prefix tables, staging
 
@@ -706,7 +718,7 @@ __global__ __launch_bounds__(kKsThreads, 2) void ksel_kernel(SearchArgs<float> a
         }
     }
     if (WTP_DIAG && a.diag && lane == 0) {
-        for (int i = 0; i < 8; ++i) atomicAdd(&a.diag[i], dt[i]);
+        for (int i = 0; i < 11; ++i) atomicAdd(&a.diag[i], dt[i]);
         atomicAdd(&a.diag[15], 1ull);
     }
     if (MODE == 1) {

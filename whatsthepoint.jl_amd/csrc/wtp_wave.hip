@@ -108,7 +108,8 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
         bool cs_try = cs_r > 0, cs_done = false;
         // hand-backs of the brick kernels already failed at 27 cells: start at 5^3; whole-cloud runs
         // (fp64, stale snapshots) start at the 27 cells, which certify most queries
-        for (int r2 = all ? 1 : 2;;) {
+        // (hand-backs of wtp_ksel.hip failed at 5^3 of its small cells: they start at 7^3, a.fb_r0 = 3)
+        for (int r2 = all ? 1 : (a.fb_r0 > 0 ? a.fb_r0 : 2);;) {
             const int r = cs_try ? cs_r : r2;
             m = 0;
             // the support-ball attempt gathers everything the block certifies (>= the ball), so that a query
