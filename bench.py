@@ -124,7 +124,7 @@ def other_paths(ctx, torch, np, wtp_amd, extra_legs=False, e2e=True):
     dt = (time.perf_counter() - t0) / reps
     out["knn_topology_k21_1M"] = {"value": round(n / dt / 1e6, 1), "unit": "Mpoints/s", "ms": round(dt * 1e3, 3),
                                   "alg_gbs": round(151.0 * n / dt / 1e9, 1),
-                                  "note": "wtp_knn_dev: hash + brick_kernel<0,21,0>, rows int32 on device"}
+                                  "note": "wtp_knn_dev: hash + ksel_kernel<0,21> (wtp_ksel.hip: x-slowest halo, hit masks, 64-key network), rows int32 on device"}
     xh = x.cpu().numpy()
     del x, idx
     r = (21.0 / (4.0 / 3.0 * np.pi * n)) ** (1.0 / 3.0)
@@ -625,7 +625,7 @@ def main():
             sw2 = tm2["sweep_ms"] / max(tm2["sweep_launches"], 1)
             full_sel = {"value": round(n_local * args.steps / dt2 / 1e6, 3), "unit": "Mpoints/s",
                         "ms_per_step": round(dt2 / args.steps * 1e3, 4), "sweep_ms": round(sw2, 4),
-                        "kernel": "wtp::brick_kernel<1,21,0> (64-key selection network on every query)",
+                        "kernel": "wtp::ksel_kernel<1,21> (x-slowest halo, hit masks, 64-key selection network on every query)",
                         "roofline_frac": round(B_ALG_SWEEP * n_local / (sw2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
             sess2.close()
             ctx2.close()

@@ -302,6 +302,41 @@ static void ksel_geometry(wtp_ctx* ctx, double n, double ncells, int n0, double 
         fprintf(stderr, "[wtp] ksel geometry: rho_cell %.3f (box average %.3f), %d columns -> bricks of %d, LDS point area %d\n",
                 rho_cell, ncells > 0 ? n / ncells : 0.0, n0, *bx_out, *hcap_out);
 }
+// The occupancy (points per cell) that serves THIS cloud best, between 1.08 and 1.26 times k/22: the x axis holds a whole
+// number of equal bricks, so the lane fill of a brick steps with the number of columns (at 10 M points 1.2 leaves bricks of
+// 41 columns, 77 % of the lanes; 1.1 fills 90 %).  Model per query: (one brick round, two with probability p2) / Q own
+// points, times the round's cost (a scan in proportion to the occupancy on top of a fixed part), plus the hand-backs that
+// grow as the provable radius 2c shrinks.  `n0`, `c`: the grid just built with occupancy rho_cur.
+static double ksel_pick_rho(const wtp_ctx* ctx, double n, double ncells, int n0, double rho_cur, double rho_eff) {
+    if (getenv("WTP_RHO_KSEL")) return rho_cur; // the caller fixed it
+    double fill_cur = ncells > 0 ? n / ncells : rho_cur; // points per cell, box average
+    if (rho_eff - 1.0 > fill_cur) fill_cur = rho_eff - 1.0;
+    double best = 1e300, best_rho = rho_cur;
+    for (double f = 0.90; f <= 1.051; f += 0.0125) { // candidate occupancy = f * rho_cur
+        const double edge = std::cbrt(f);                 // cell edge relative to the current one
+        const int cols = (int)(((double)n0 - 0.5) / edge) + 1;
+        const double rho_cell = fill_cur * f;
+        double cost_b = 1e300;
+        for (int nbx = 1; nbx <= cols; ++nbx) {
+            const int b = (cols + nbx - 1) / nbx;
+            if (b > ksel_max_bx()) continue;
+            const double q = 4.0 * rho_cell * b;
+            const double p2 = 0.5 * std::erfc((256.0 - q) / std::sqrt(2.0 * (q > 1 ? q : 1)));
+            const double cst = (1.0 + p2 + (q > 512.0 ? 100.0 : 0.0)) / q;
+            cost_b = cst < cost_b ? cst : cost_b;
+            if (b < 8) break;
+        }
+        const double round = 0.63 + 0.37 * f;                       // per-round work: fixed part + scan
+        const double handback = 1.0 + 0.20 * (1.0 - f) / 0.1 * 0.1;   // ~2 % more total time per 10 % less occupancy
+        const double cost = cost_b * round * handback;
+        if (cost < best) {
+            best = cost;
+            best_rho = rho_cur * f;
+        }
+    }
+    return best_rho;
+}
+
 // points the first filter ball is expected to hold: k + self plus the same number of standard deviations as
 // cap_ksel leaves at 22
 static double ksel_cap_count(const wtp_ctx* ctx, int kq) {
@@ -335,7 +370,7 @@ static int knn_dev_t(wtp_ctx* ctx, const T* d_xyz, int64_t n, int dim, int k, in
     if (ctx->knn_tune_n == n && ctx->knn_tune_dim == dim && ctx->knn_tune_k == kq && !ctx->knn_tune_boxed &&
         ctx->knn_tune_ksel == (int)ksel) {
         ctx->box_active = false;
-        if ((rc = build_hash<T>(ctx, raw, sorted, n, dim, kq, 0.0, rho_direct, 0.0, ctx->knn_tune_scale))) {
+        if ((rc = build_hash<T>(ctx, raw, sorted, n, dim, kq, 0.0, ksel ? ctx->knn_tune_rho : 0.0, 0.0, ctx->knn_tune_scale))) {
             ctx->topology_build = false;
             return rc;
         }
@@ -345,6 +380,18 @@ static int knn_dev_t(wtp_ctx* ctx, const T* d_xyz, int64_t n, int dim, int k, in
         if ((rc = build_hash_tuned<T>(ctx, raw, sorted, n, dim, kq, 0.0, rho_direct, 0.0, &scale, &rho_eff, &hg))) {
             ctx->topology_build = false;
             return rc;
+        }
+        ctx->knn_tune_rho = rho_direct;
+        if (ksel) { // the occupancy whose grid fills the bricks' lanes best: one more measured build, this call only
+            const double pick = ksel_pick_rho(ctx, (double)n, (double)hg.ncells, hg.n[0], rho_direct, rho_eff);
+            if (std::fabs(pick - rho_direct) > 0.01 * rho_direct) {
+                scale = 1.0;
+                if ((rc = build_hash_tuned<T>(ctx, raw, sorted, n, dim, kq, 0.0, pick, 0.0, &scale, &rho_eff, &hg))) {
+                    ctx->topology_build = false;
+                    return rc;
+                }
+                ctx->knn_tune_rho = pick;
+            }
         }
         ctx->knn_tune_n = n;
         ctx->knn_tune_dim = dim;
@@ -1138,7 +1185,7 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
         const bool ksel_ok = sizeof(T) == 4 && r.dim == 3 && ctx->ksel && !ctx->force_generic && r.k >= 2 &&
                              r.k <= ksel_kmax() && r.n >= 4096;
         r.ksel_sweep = !r.cs_sweep && ksel_ok;
-        if (r.ksel_sweep) rho_cs = ctx->rho_ksel * (double)r.k / 22.0;
+        if (r.ksel_sweep) rho_cs = r.grid_tuned && r.ksel_rho > 0 ? r.ksel_rho : ctx->rho_ksel * (double)r.k / 22.0;
         if (r.spacing_typ <= 0) { // once per session: the spacing a typical point asks for
             r.spacing_typ = r.spacing_const;
             if (r.spacing_kind != WTP_SPACING_CONSTANT) {
@@ -1195,7 +1242,18 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
                 hc = (hc + 63) / 64 * 64;
                 r.brick_hcap = hc < 640 ? 640 : (hc > 2560 ? 2560 : hc);
             }
-            if (r.ksel_sweep) ksel_geometry(ctx, (double)r.n, (double)hg.ncells, hg.n[0], rho_eff, &r.ksel_bx, &r.ksel_hcap);
+            if (r.ksel_sweep) {
+                const double pick = ksel_pick_rho(ctx, (double)r.n, (double)hg.ncells, hg.n[0], rho_cs, rho_eff);
+                if (std::fabs(pick - rho_cs) > 0.01 * rho_cs) {
+                    rho_cs = pick;
+                    r.cell_scale = 1.0;
+                    rc = build_hash_tuned<T>(ctx, (const Pt<T>*)ctx->pts[r.bufP].p, (Pt<T>*)ctx->pts[t].p, r.n, r.dim, r.k, 0.0,
+                                             rho_cs, min_cell, &r.cell_scale, &rho_eff, &hg);
+                    if (rc) return rc;
+                }
+                r.ksel_rho = rho_cs;
+                ksel_geometry(ctx, (double)r.n, (double)hg.ncells, hg.n[0], rho_eff, &r.ksel_bx, &r.ksel_hcap);
+            }
             r.grid_tuned = true;
             r.tuned_fixed = r.n_fixed;
             r.grid_fixed = r.n_fixed;

@@ -181,6 +181,7 @@ struct RelaxState {
     bool cs_disabled = false; // measured on the first rebuild: support cells would be over-full, use the k-selection sweep
     bool ksel_sweep = false; // k-selection sweep on the x-slowest layout (wtp_ksel.hip)
     int ksel_bx = 0, ksel_hcap = 0; // its brick length along x and LDS point area, measured with the grid
+    double ksel_rho = 0;     // the occupancy picked for this cloud (ksel_pick_rho)
     int cs2_bx = 0;          // > 0: the round-2 compact-support sweep (wtp_cs2.hip) with bricks of this many cells along x
     int64_t tuned_fixed = 0; // fixed points the grid / brick geometry was measured with (a swapped head re-measures when it differs by > 5 % of n)
     double sp_p0 = 0, sp_p1 = 0, sp_p2 = 0; // LOGLIKE / BOUNDARY_LAYER parameters
@@ -224,6 +225,7 @@ struct wtp_ctx {
     // properties of a kernel on one device, and several contexts (devices) may live in one process
     std::map<std::pair<const void*, size_t>, int> launch_cache;
     double styp_sigma = 0.0;   // WTP_STYP_SIGMA: typical spacing = mean + this many standard deviations (measured: > 0 only hurts)
+    double knn_tune_rho = 0;   // occupancy the wtp_ksel.hip grid of that cloud was built with
     int knn_tune_ksel = -1, knn_tune_bx = 0, knn_tune_hcap = 0; // wtp_ksel.hip layout in use for that cloud, its brick geometry
     int64_t knn_tune_n = -1;   // topology calls: cloud size / dim / k the cached cell scale was measured for
     int knn_tune_dim = 0, knn_tune_k = 0;

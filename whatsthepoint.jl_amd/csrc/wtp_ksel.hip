@@ -172,13 +172,13 @@ __global__ __launch_bounds__(kKsThreads, 2) void ksel_kernel(SearchArgs<float> a
     };
 
     // the first 64 points of each of the wave's rows (longer rows: the rest at staging time)
-    auto load_points = [&](const int (&vv)[kKsRows], float4 (&pp)[kKsRows]) {
+    auto load_points = [&](const int (&vv)[kKsRows], float4 (&pp)[kKsRows], int ln) {
         const int last = a.n - 1;
 #pragma unroll
         for (int j = 0; j < kKsRows; ++j) {
             const int gs = __builtin_amdgcn_readfirstlane(vv[j]);
             const int len = __builtin_amdgcn_readlane(vv[j], HX) - gs;
-            const int i = gs + (lane < len ? lane : 0);
+            const int i = gs + (ln < len ? ln : 0);
             pp[j] = a.snap[i < last ? i : last];
         }
     };
@@ -188,6 +188,11 @@ __global__ __launch_bounds__(kKsThreads, 2) void ksel_kernel(SearchArgs<float> a
     for (int j = 0; j < kKsRows; ++j) v[j] = 0;
     if (brick < b_end) load_cells(brick_pos(brick), v);
     for (; brick < b_end; brick += blk_per_group) {
+        // lane / thread index as the table phase sees them: opaque per brick, so the LDS addresses built from them are
+        // recomputed here instead of being hoisted out of the brick loop and spilled across the queries (a spill reload in
+        // this phase costs a `s_waitcnt vmcnt(0)`, i.e. the full latency of the rows' point loads in flight)
+        int ln = lane, tv = tid;
+        asm volatile("" : "+v"(ln), "+v"(tv));
         const BrickPos pos = brick_pos(brick);
         const int ox = pos.bx * BX - 2, oy = pos.by * 2 - 2, oz = pos.bz * 2 - 2; // halo origin (cell coordinates)
         const int next = brick + blk_per_group;
@@ -199,34 +204,34 @@ __global__ __launch_bounds__(kKsThreads, 2) void ksel_kernel(SearchArgs<float> a
         //         the column's cells in rows before r — is a sum of cell_start values: no scan across lanes ----------
         int cn[kKsRows], row_gs[kKsRows], row_len[kKsRows];
         float4 pv[kKsRows];
-        load_points(v, pv); // in flight while the tables are built (held across the queries of the previous brick they cost
+        load_points(v, pv, ln); // in flight while the tables are built (held across the queries of the previous brick they cost
                             // more in spills than the wait they save: measured)
         {
             int vs = 0, cs = 0;
 #pragma unroll
             for (int j = 0; j < kKsRows; ++j) {
-                const int nxt = __shfl_down(v[j], 1, 64);
-                cn[j] = lane < HX ? nxt - v[j] : 0;
+                const int nxt = __builtin_amdgcn_ds_bpermute(((ln + 1) & 63) << 2, v[j]); // (the library shuffles rebuild the lane id: one more value kept across the queries)
+                cn[j] = ln < HX ? nxt - v[j] : 0;
                 row_gs[j] = __builtin_amdgcn_readfirstlane(v[j]);
                 row_len[j] = __builtin_amdgcn_readlane(v[j], HX) - row_gs[j];
                 vs += v[j];
                 cs += cn[j];
             }
-            if (lane <= HX) {
-                sm->wsum[wave][lane] = (uint32_t)vs;
-                sm->wcnt[wave][lane] = (uint32_t)cs;
+            if (ln <= HX) {
+                sm->wsum[wave][ln] = (uint32_t)vs;
+                sm->wcnt[wave][ln] = (uint32_t)cs;
                 // own rows: r = 14, 15 (wave 1, j = 5, 6) and r = 20, 21 (wave 2, j = 2, 3)
-                if (wave == 1) sm->wown[0][lane] = (uint32_t)(v[5] + v[6]);
-                if (wave == 2) sm->wown[1][lane] = (uint32_t)(v[2] + v[3]);
+                if (wave == 1) sm->wown[0][ln] = (uint32_t)(v[5] + v[6]);
+                if (wave == 2) sm->wown[1][ln] = (uint32_t)(v[2] + v[3]);
             }
-            if (lane >= 2 && lane < HX - 2) {
+            if (ln >= 2 && ln < HX - 2) {
                 if (wave == 1) {
-                    sm->hown[lane][0] = (uint32_t)v[5];
-                    sm->hown[lane][1] = (uint32_t)v[6];
+                    sm->hown[ln][0] = (uint32_t)v[5];
+                    sm->hown[ln][1] = (uint32_t)v[6];
                 }
                 if (wave == 2) {
-                    sm->hown[lane][2] = (uint32_t)v[2];
-                    sm->hown[lane][3] = (uint32_t)v[3];
+                    sm->hown[ln][2] = (uint32_t)v[2];
+                    sm->hown[ln][3] = (uint32_t)v[3];
                 }
             }
         }
@@ -237,33 +242,33 @@ __global__ __launch_bounds__(kKsThreads, 2) void ksel_kernel(SearchArgs<float> a
             uint32_t left = 0, g0 = 0, before = 0, tot = 0;
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                left += sm->wsum[w][lane <= HX ? lane : 0];
+                left += sm->wsum[w][ln <= HX ? ln : 0];
                 g0 += sm->wsum[w][0];
                 tot += sm->wsum[w][HX];
-                before += w < wave ? sm->wcnt[w][lane <= HX ? lane : 0] : 0u;
+                before += w < wave ? sm->wcnt[w][ln <= HX ? ln : 0] : 0u;
             }
             halo_total = (int)(tot - g0);
-            if (lane < HX) {
+            if (ln < HX) {
                 uint32_t e = left - g0 + before;
 #pragma unroll
                 for (int j = 0; j < kKsRows; ++j) {
-                    sm->ls[lane * kKsSlab + wave * kKsRows + j] = (uint16_t)(e > 0xFFFFu ? 0xFFFFu : e);
+                    sm->ls[ln * kKsSlab + wave * kKsRows + j] = (uint16_t)(e > 0xFFFFu ? 0xFFFFu : e);
                     e += (uint32_t)cn[j];
                 }
             }
-            if (tid == 0) sm->ls[ncell] = (uint16_t)(halo_total > 0xFFFF ? 0xFFFF : halo_total);
+            if (tv == 0) sm->ls[ncell] = (uint16_t)(halo_total > 0xFFFF ? 0xFFFF : halo_total);
             // own queries in front of slab hx (slabs 2 .. BX+1 hold own cells; entry BX+2 closes the table)
-            if (wave == 3 && lane >= 2 && lane <= BX + 2) {
-                const uint32_t q = (sm->wown[0][lane] + sm->wown[1][lane]) - (sm->wown[0][2] + sm->wown[1][2]);
-                sm->qpref[lane] = (uint16_t)(q > 0xFFFFu ? 0xFFFFu : q);
+            if (wave == 3 && ln >= 2 && ln <= BX + 2) {
+                const uint32_t q = (sm->wown[0][ln] + sm->wown[1][ln]) - (sm->wown[0][2] + sm->wown[1][2]);
+                sm->qpref[ln] = (uint16_t)(q > 0xFFFFu ? 0xFFFFu : q);
             }
         }
         __syncthreads();
         KS_STAMP(9) // prefix tables
         const bool overflow = halo_total > hcap;
-        if (tid >= 2 && tid <= BX + 1) {
-            const int q0 = sm->qpref[tid], q1 = sm->qpref[tid + 1];
-            for (int q = q0; q < q1 && q < kKsMaxQ; ++q) sm->qslab[q] = (uint8_t)tid;
+        if (tv >= 2 && tv <= BX + 1) {
+            const int q0 = sm->qpref[tv], q1 = sm->qpref[tv + 1];
+            for (int q = q0; q < q1 && q < kKsMaxQ; ++q) sm->qslab[q] = (uint8_t)tv;
         }
         // ---- 2. stage the halo: global rows are contiguous, the LDS order is (hx, hz, hy) ---------------
         if (!overflow) {
@@ -272,21 +277,21 @@ __global__ __launch_bounds__(kKsThreads, 2) void ksel_kernel(SearchArgs<float> a
             auto place = [&](const float4 p, int i, int j, int vj) { // i: index in the row; every lane takes part (cross-lane read)
                 int hx = cell_coord(g, p.x, 0) - ox;
                 hx = hx < 0 ? 0 : (hx > HX - 1 ? HX - 1 : hx);
-                const int cell_gs = __shfl(vj, hx, 64);
+                const int cell_gs = __builtin_amdgcn_ds_bpermute(hx << 2, vj);
                 int dest = (int)sm->ls[hx * kKsSlab + wave * kKsRows + j] + (row_gs[j] + i - cell_gs);
                 dest = dest < 0 ? 0 : (dest > hcap - 1 ? hcap - 1 : dest); // never outside the point area
                 if (i < row_len[j]) pts[dest] = p;
             };
 #pragma unroll
-            for (int j = 0; j < kKsRows; ++j) place(pv[j], lane, j, v[j]);
+            for (int j = 0; j < kKsRows; ++j) place(pv[j], ln, j, v[j]);
 #pragma unroll
             for (int j = 0; j < kKsRows; ++j) // rows longer than a wave: the rest, row by row
                 for (int i0 = 64; i0 < row_len[j]; i0 += 64) {
-                    const int i = i0 + lane;
+                    const int i = i0 + ln;
                     place(a.snap[row_gs[j] + (i < row_len[j] ? i : 0)], i, j, v[j]);
                 }
             // one scan step past the staged points: far sentinels instead of another brick's leftovers
-            if (tid < 2 * kKsSU) pts[halo_total + tid] = make_float4(1e30f, 1e30f, 1e30f, 0.f);
+            if (tv < 2 * kKsSU) pts[halo_total + tv] = make_float4(1e30f, 1e30f, 1e30f, 0.f);
         }
         // the next brick's cell table: in flight while this brick's queries run
         if (next < b_end) load_cells(brick_pos(next), v);
