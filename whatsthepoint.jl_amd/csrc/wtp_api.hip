@@ -416,7 +416,10 @@ static int knn_dev_t(wtp_ctx* ctx, const T* d_xyz, int64_t n, int dim, int k, in
     a.fb_list = (int32_t*)ctx->fb_list.p;
     a.fb_count = (int32_t*)ctx->fb_count.p;
     a.fb2_list = (int32_t*)ctx->fb2_list.p;
-    a.fb2_count = (int32_t*)ctx->fb2_count.p;
+    // one 64-byte counter block, cleared once: [0] hand-backs of the brick kernel, [4] of the wave kernel
+    a.fb2_count = (int32_t*)ctx->fb_count.p + 4;
+    WTP_HIP(ctx, hipMemsetAsync(ctx->fb_count.p, 0, 64, ctx->stream));
+    a.counters_cleared = 1;
     if ((rc = ensure(ctx, ctx->diag, 128))) return rc;
     a.diag = (unsigned long long*)ctx->diag.p; // (written by -DWTP_DIAG builds only)
     if (ksel) {

@@ -934,7 +934,7 @@ int launch_brick_radius(wtp_ctx* ctx, SearchArgs<float>& a) {
 template <> int launch_topology<float>(wtp_ctx* ctx, SearchArgs<float>& a) {
     if (a.k > kFastKMax - 1 || ctx->force_generic) return launch_generic_topology<float>(ctx, a, true);
     if (a.ksel_bx > 0) { // the caller built the grid for the x-slowest layout (wtp_ksel.hip)
-        WTP_HIP(ctx, hipMemsetAsync(a.fb_count, 0, sizeof(int32_t), ctx->stream));
+        if (!a.counters_cleared) WTP_HIP(ctx, hipMemsetAsync(a.fb_count, 0, sizeof(int32_t), ctx->stream));
         const int rk = launch_ksel_topology(ctx, a);
         if (rk) return rk;
         a.fb_r0 = 3;
@@ -942,7 +942,7 @@ template <> int launch_topology<float>(wtp_ctx* ctx, SearchArgs<float>& a) {
     }
     a.gamma_cap = (float)ctx->gamma_cap;
     a.cap_count = (float)(4.18879 * ctx->gamma_cap * ctx->gamma_cap * ctx->gamma_cap * ctx->rho * (a.k + 1) / 22.0);
-    WTP_HIP(ctx, hipMemsetAsync(a.fb_count, 0, sizeof(int32_t), ctx->stream));
+    if (!a.counters_cleared) WTP_HIP(ctx, hipMemsetAsync(a.fb_count, 0, sizeof(int32_t), ctx->stream));
     int rc = a.k == 21 ? brick_launch<0, 21, 0>(ctx, a) : brick_launch<0, 0, 0>(ctx, a);
     if (rc) return rc;
     return launch_generic_topology<float>(ctx, a, false);

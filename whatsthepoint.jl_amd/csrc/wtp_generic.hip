@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kThreads) void radius_kernel(SearchArgs<T> a, T r, 
 // whatever the wave kernel could not buffer (fb2 list).  WTP_FORCE_GENERIC=2 runs everything
 // through the serial kernel (debug).
 template <typename T> int launch_generic_topology(wtp_ctx* ctx, SearchArgs<T>& a, bool all) {
-    WTP_HIP(ctx, hipMemsetAsync(a.fb2_count, 0, sizeof(int32_t), ctx->stream));
+    if (!a.counters_cleared) WTP_HIP(ctx, hipMemsetAsync(a.fb2_count, 0, sizeof(int32_t), ctx->stream));
     if (ctx->force_generic == 2) {
         hipLaunchKernelGGL((generic_kernel<T, 0>), dim3(blocks_for(a.n, all ? 65536 : 1024)), dim3(kThreads), 0,
                            ctx->stream, a, a.fb_list, a.fb_count, all ? 1 : 0, 0);

@@ -205,7 +205,7 @@ __global__ void cell_rank_kernel(const Pt<T>* __restrict__ pts, int64_t n, const
             // A run keeps the order of the input (ids ascending inside a cell: the original order, or the previous
             // canonical one).  Only a cell that collects SEVERAL runs (a point moved in, or a run split between two
             // waves) can end up out of order: the canonical-order pass visits those cells only.
-            if (r0 != 0) dirty[cell] = 1;
+            if (r0 != 0 && dirty) dirty[cell] = 1; // (topology builds pass no map: their rows are ordered by (d2, id) explicitly)
         }
         r0 = __shfl(r0, start, 64);
         if (valid) cell_rank[i] = r0 + (lane - start); // the cell itself is recomputed by the scatter (4 bytes per point less, twice)
@@ -741,8 +741,8 @@ int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, in
     }
     ctx->ncells_dev = &g->ncells;
     const int nb = grid_for(n_in, kThreads, 16384);
-    hipLaunchKernelGGL(cell_rank_kernel<T>, dim3(nb), dim3(kThreads), 0, st, in, n_in, g, cnt, cr, dirty, v_old, v_fixed_old,
-                       ctx->stop_dev);
+    hipLaunchKernelGGL(cell_rank_kernel<T>, dim3(nb), dim3(kThreads), 0, st, in, n_in, g, cnt, cr,
+                       ctx->topology_build ? (uint8_t*)nullptr : dirty, v_old, v_fixed_old, ctx->stop_dev);
     hipLaunchKernelGGL(scan_reduce_kernel<T>, dim3(nscan), dim3(kThreads), 0, st, cnt, g, bs);
     hipLaunchKernelGGL(scan_apply_kernel<T>, dim3(nscan), dim3(kThreads), 0, st, cnt, bs, g, start, ctx->stop_dev);
     hipLaunchKernelGGL(scatter_kernel<T>, dim3(nb), dim3(kThreads), 0, st, in, n_in, cr, g, start, out, v_old, v_fixed_old,
@@ -752,7 +752,7 @@ int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, in
                            dirty, g, ctx->stop_dev);
     }
     WTP_HIP(ctx, hipGetLastError());
-    ctx->hash_scratch_clean = !ctx->topology_build; // (without the canonical-order pass the dirty marks stay: the next build clears them)
+    ctx->hash_scratch_clean = true; // (the scan consumed the counts; a topology build wrote no marks, the canonical-order pass cleared the others)
     return WTP_OK;
 }
 

@@ -135,6 +135,7 @@ template <typename T> struct SearchArgs {
     T tnn_frac;                // CS sweeps: nearest-neighbour margin of the ring, in cell edges (WTP_TNN, default 0.8)
     int32_t brick_hcap;        // LDS point capacity for the brick kernel (0 = default)
     int32_t cs2_bx;            // > 0: brick length (own cells along x) of the round-2 compact-support sweep (wtp_cs2.hip)
+    int32_t counters_cleared;  // topology calls: the caller cleared fb_count / fb2_count (one 64-byte block) itself
     int32_t fb_r0;             // first block radius (cells) of the exact path for hand-backs; 0: the default (2: the 27 cells failed already)
     int32_t ksel_bx;           // > 0: the grid was built for the k-selection kernels of wtp_ksel.hip; largest brick length along x
     unsigned long long* diag;  // -DWTP_DIAG builds: per-phase wave-cycle sums (8 slots), else unused
