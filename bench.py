@@ -539,18 +539,33 @@ def main():
             boxes = blockc.orthtree_boxes(None, world, equal_count=False)
             own_xyz, own_gid = blockc.shard_stream(gen, boxes, rank, n_total)
             transport = None
+            transport_note = "RCCL (the library's own communicator: grouped ncclSend / ncclRecv, device buffers)"
             if rehearsal:
                 transport = blockc.dist_transport(dist, rank, world)
+                transport_note = "rehearsal: host-staged over gloo"
             else:  # the context's own RCCL communicator; torch only carries the 128-byte id
-                box = [ctx.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                ctx.comm_init(box[0], rank, world)
+                ok, why = 1, ""
+                try:
+                    box = [ctx.comm_unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(box, src=0)
+                    ctx.comm_init(box[0], rank, world)
+                except Exception as e:  # noqa: BLE001 - every rank must learn about it
+                    ok, why = 0, str(e)
+                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    # the measurement must not be lost to a communicator that does not come up on this node: the same
+                    # driver over the host-callback transport (rows staged through host memory, gloo) — and the line says so
+                    print(f"[bench] rank {rank}: library RCCL communicator unavailable ({why or 'another rank failed'}); "
+                          f"falling back to the host-staged transport", file=sys.stderr)
+                    transport = blockc.dist_transport(dist, rank, world, group=dist.new_group(backend="gloo"))
+                    transport_note = "FALLBACK: host-staged over gloo (the library's RCCL communicator did not come up)"
             cdrv = blockc.BlockRelax(ctx, rank, world, boxes, own_xyz, own_gid, sharded.ghost_width(n_total, k, ctx_rho()), s,
                                      force, k, s / 2000, s / 20, transport=transport)
             del own_xyz, own_gid
             g3 = blockc.block_grid(world)
             shard_note = (f"{g3[0]} x {g3[1]} x {g3[2]} orthtree boxes (Morton rank order), C block driver: one grouped "
-                          f"send/recv round per iteration, counts riding the statistics all-gather")
+                          f"send/recv round per iteration, counts riding the statistics all-gather; transport: {transport_note}")
 
             class _Drv:
                 last = None

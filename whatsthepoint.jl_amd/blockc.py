@@ -286,14 +286,14 @@ def loopback_transport(hub: LoopbackHub, rank: int) -> _Transport:
     return _Transport(allgather, exchange)
 
 
-def dist_transport(dist, rank: int, world: int) -> _Transport:
-    """The same two callbacks over torch.distributed with CPU tensors (gloo)."""
+def dist_transport(dist, rank: int, world: int, group=None) -> _Transport:
+    """The same two callbacks over torch.distributed with CPU tensors (gloo; `group`: a gloo group next to an nccl default one)."""
     import torch
 
     def allgather(user, send, recv, nbytes):
         mine = torch.frombuffer(bytearray(C.string_at(send, nbytes)), dtype=torch.uint8)
         out = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(out, mine)
+        dist.all_gather(out, mine, group=group)
         C.memmove(recv, b"".join(bytes(t.numpy().tobytes()) for t in out), nbytes * world)
         return 0
 
@@ -302,11 +302,11 @@ def dist_transport(dist, rank: int, world: int) -> _Transport:
         for j in range(n_msgs):
             if send_bytes[j]:
                 t = torch.frombuffer(bytearray(C.string_at(send[j], send_bytes[j])), dtype=torch.uint8)
-                ops.append(dist.P2POp(dist.isend, t, int(peers[j])))
+                ops.append(dist.P2POp(dist.isend, t, int(peers[j]), group=group))
             if recv_bytes[j]:
                 r = torch.empty(int(recv_bytes[j]), dtype=torch.uint8)
                 bufs.append((j, r))
-                ops.append(dist.P2POp(dist.irecv, r, int(peers[j])))
+                ops.append(dist.P2POp(dist.irecv, r, int(peers[j]), group=group))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()

@@ -263,11 +263,14 @@ __global__ __launch_bounds__(kKsThreads, 2) void ksel_kernel(SearchArgs<float> a
                 sm->qpref[ln] = (uint16_t)(q > 0xFFFFu ? 0xFFFFu : q);
             }
         }
-        __syncthreads();
+        // (no barrier here: what follows reads table entries its own wave wrote — the `ls` of its nine rows — or the column
+        // sums that were complete at the barrier above; the other waves' entries are read after the staging barrier)
         KS_STAMP(9) // prefix tables
         const bool overflow = halo_total > hcap;
         if (tv >= 2 && tv <= BX + 1) {
-            const int q0 = sm->qpref[tv], q1 = sm->qpref[tv + 1];
+            const uint32_t qb0 = sm->wown[0][2] + sm->wown[1][2];
+            const uint32_t qa = (sm->wown[0][tv] + sm->wown[1][tv]) - qb0, qe = (sm->wown[0][tv + 1] + sm->wown[1][tv + 1]) - qb0;
+            const int q0 = (int)(qa > 0xFFFFu ? 0xFFFFu : qa), q1 = (int)(qe > 0xFFFFu ? 0xFFFFu : qe);
             for (int q = q0; q < q1 && q < kKsMaxQ; ++q) sm->qslab[q] = (uint8_t)tv;
         }
         // ---- 2. stage the halo: global rows are contiguous, the LDS order is (hx, hz, hy) ---------------
