@@ -313,6 +313,7 @@ static double ksel_pick_rho(const wtp_ctx* ctx, double n, double ncells, int n0,
     if (rho_eff - 1.0 > fill_cur) fill_cur = rho_eff - 1.0;
     double best = 1e300, best_rho = rho_cur;
     for (double f = 0.90; f <= 1.051; f += 0.0125) { // candidate occupancy = f * rho_cur
+        if (rho_cur * f > 1.27) continue;                 // (a run of 173 cells must fit the 256 slots of the hit masks)
         const double edge = std::cbrt(f);                 // cell edge relative to the current one
         const int cols = (int)(((double)n0 - 0.5) / edge) + 1;
         const double rho_cell = fill_cur * f;
@@ -337,6 +338,12 @@ static double ksel_pick_rho(const wtp_ctx* ctx, double n, double ncells, int n0,
     return best_rho;
 }
 
+// occupancy of the wtp_ksel.hip grid for kq = k + self: in proportion to kq (the cell edge follows r_k), capped where a run of
+// 173 cells still fits the 256 slots of the hit masks
+static double ksel_rho_for(const wtp_ctx* ctx, int kq) {
+    const double rho = ctx->rho_ksel * (double)kq / 22.0;
+    return rho > 1.26 ? 1.26 : rho;
+}
 // points the first filter ball is expected to hold: k + self plus the same number of standard deviations as
 // cap_ksel leaves at 22
 static double ksel_cap_count(const wtp_ctx* ctx, int kq) {
@@ -365,7 +372,7 @@ static int knn_dev_t(wtp_ctx* ctx, const T* d_xyz, int64_t n, int dim, int k, in
     // fp32 3-D clouds with k + self <= 22 (the reference's k = 21 among them): the x-slowest layout of wtp_ksel.hip —
     // cells of ~1.2 points, the k nearest inside the 5 x 5 x 5 block around the query's cell
     const bool ksel = sizeof(T) == 4 && dim == 3 && ctx->ksel && !ctx->force_generic && kq <= ksel_kmax() && n >= 4096;
-    const double rho_direct = ksel ? ctx->rho_ksel * (double)kq / 22.0 : 0.0;
+    const double rho_direct = ksel ? ksel_rho_for(ctx, kq) : 0.0;
     ctx->topology_build = true;
     if (ctx->knn_tune_n == n && ctx->knn_tune_dim == dim && ctx->knn_tune_k == kq && !ctx->knn_tune_boxed &&
         ctx->knn_tune_ksel == (int)ksel) {
@@ -482,8 +489,39 @@ static int knn_dev_f64(wtp_ctx* ctx, const double* d_xyz, int64_t n, int dim, in
     if ((rc = launch_to_local_f32(ctx, raw64, n, org4, raw32))) return rc;
     double scale = 1.0, rho_eff = 0;
     Grid<float> hg;
+    // the fp32 candidate search takes the x-slowest layout of wtp_ksel.hip where that applies (3-D, k + self + 2 <= 24)
+    const bool ksel = dim == 3 && ctx->ksel && kc <= ksel_kmax() && n >= 4096;
+    double rho_direct = ksel ? ksel_rho_for(ctx, kc) : 0.0;
     ctx->topology_build = true;
-    rc = build_hash_tuned<float>(ctx, raw32, sorted32, n, dim, kc, 0.0, 0.0, 0.0, &scale, &rho_eff, &hg);
+    // the measured cell scale (and the brick geometry that goes with it) of the last fp64 call is reused for a cloud of the
+    // same size, as in the fp32 calls: it only affects speed, and saves two occupancy passes and a host synchronisation
+    const bool cached = ctx->knn64_tune_n == n && ctx->knn64_tune_dim == dim && ctx->knn64_tune_k == kc &&
+                        ctx->knn64_tune_ksel == (int)ksel;
+    if (cached) {
+        ctx->box_active = false;
+        rc = build_hash<float>(ctx, raw32, sorted32, n, dim, kc, 0.0, ksel ? ctx->knn64_tune_rho : 0.0, 0.0, ctx->knn64_tune_scale);
+    } else {
+        rc = build_hash_tuned<float>(ctx, raw32, sorted32, n, dim, kc, 0.0, rho_direct, 0.0, &scale, &rho_eff, &hg);
+        if (!rc && ksel) {
+            const double pick = ksel_pick_rho(ctx, (double)n, (double)hg.ncells, hg.n[0], rho_direct, rho_eff);
+            if (std::fabs(pick - rho_direct) > 0.01 * rho_direct) {
+                rho_direct = pick;
+                scale = 1.0;
+                rc = build_hash_tuned<float>(ctx, raw32, sorted32, n, dim, kc, 0.0, rho_direct, 0.0, &scale, &rho_eff, &hg);
+            }
+        }
+        if (!rc && !ctx->box_active) { // (a clipped box belongs to this very cloud: never reused)
+            ctx->knn64_tune_n = n;
+            ctx->knn64_tune_dim = dim;
+            ctx->knn64_tune_k = kc;
+            ctx->knn64_tune_ksel = (int)ksel;
+            ctx->knn64_tune_scale = scale;
+            ctx->knn64_tune_rho = rho_direct;
+            if (ksel) ksel_geometry(ctx, (double)n, (double)hg.ncells, hg.n[0], rho_eff, &ctx->knn64_tune_bx, &ctx->knn64_tune_hcap);
+        } else {
+            ctx->knn64_tune_n = -1;
+        }
+    }
     ctx->topology_build = false;
     if (rc) return rc;
     span_end(ctx, sp);
@@ -502,6 +540,13 @@ static int knn_dev_f64(wtp_ctx* ctx, const double* d_xyz, int64_t n, int dim, in
     a.fb_count = (int32_t*)ctx->fb_count.p;
     a.fb2_list = (int32_t*)ctx->fb2_list.p;
     a.fb2_count = (int32_t*)ctx->fb2_count.p;
+    if (ksel) {
+        if (ctx->knn64_tune_n != n) // (a clipped box: geometry of this very build)
+            ksel_geometry(ctx, (double)n, (double)hg.ncells, hg.n[0], rho_eff, &ctx->knn64_tune_bx, &ctx->knn64_tune_hcap);
+        a.ksel_bx = ctx->knn64_tune_bx;
+        a.brick_hcap = ctx->knn64_tune_hcap;
+        a.cap_count = (float)ksel_cap_count(ctx, kc);
+    }
     sp = span_begin(ctx, 1);
     rc = launch_topology<float>(ctx, a);
     if (rc) return rc;
@@ -519,7 +564,10 @@ static int knn_dev_f64(wtp_ctx* ctx, const double* d_xyz, int64_t n, int dim, in
     if (n_fail > 0) { // exact fp64 path for the uncertified queries: wave kernel over their ids, fp64 grid
         double4* sorted64 = (double4*)ctx->pts[1].p;
         ctx->box_active = false;
-        if ((rc = build_hash<double>(ctx, raw64, sorted64, n, dim, kq, 0.0))) return rc;
+        ctx->topology_build = true; // rows are ordered by (d2, id) explicitly: no canonical-order pass (0.5 ms on unsorted input)
+        rc = build_hash<double>(ctx, raw64, sorted64, n, dim, kq, 0.0);
+        ctx->topology_build = false;
+        if (rc) return rc;
         SearchArgs<double> b{};
         b.grid = (const Grid<double>*)ctx->grid.p;
         b.snap = sorted64;
@@ -1188,7 +1236,7 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
         const bool ksel_ok = sizeof(T) == 4 && r.dim == 3 && ctx->ksel && !ctx->force_generic && r.k >= 2 &&
                              r.k <= ksel_kmax() && r.n >= 4096;
         r.ksel_sweep = !r.cs_sweep && ksel_ok;
-        if (r.ksel_sweep) rho_cs = r.grid_tuned && r.ksel_rho > 0 ? r.ksel_rho : ctx->rho_ksel * (double)r.k / 22.0;
+        if (r.ksel_sweep) rho_cs = r.grid_tuned && r.ksel_rho > 0 ? r.ksel_rho : ksel_rho_for(ctx, r.k);
         if (r.spacing_typ <= 0) { // once per session: the spacing a typical point asks for
             r.spacing_typ = r.spacing_const;
             if (r.spacing_kind != WTP_SPACING_CONSTANT) {
@@ -1228,7 +1276,7 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
                 r.cs_disabled = true;
                 r.cs_sweep = false;
                 r.ksel_sweep = ksel_ok;
-                rho_cs = r.ksel_sweep ? ctx->rho_ksel * (double)r.k / 22.0 : 0.0;
+                rho_cs = r.ksel_sweep ? ksel_rho_for(ctx, r.k) : 0.0;
                 min_cell = 0.0;
                 r.cell_scale = 1.0;
                 rc = build_hash_tuned<T>(ctx, (const Pt<T>*)ctx->pts[r.bufP].p, (Pt<T>*)ctx->pts[t].p, r.n, r.dim, r.k, 0.0,

@@ -226,6 +226,10 @@ struct wtp_ctx {
     // properties of a kernel on one device, and several contexts (devices) may live in one process
     std::map<std::pair<const void*, size_t>, int> launch_cache;
     double styp_sigma = 0.0;   // WTP_STYP_SIGMA: typical spacing = mean + this many standard deviations (measured: > 0 only hurts)
+    // the same cache for the fp32 candidate search of fp64 topology calls (knn_dev_f64)
+    int64_t knn64_tune_n = -1;
+    int knn64_tune_dim = 0, knn64_tune_k = 0, knn64_tune_ksel = -1, knn64_tune_bx = 0, knn64_tune_hcap = 0;
+    double knn64_tune_scale = 1.0, knn64_tune_rho = 0;
     double knn_tune_rho = 0;   // occupancy the wtp_ksel.hip grid of that cloud was built with
     int knn_tune_ksel = -1, knn_tune_bx = 0, knn_tune_hcap = 0; // wtp_ksel.hip layout in use for that cloud, its brick geometry
     int64_t knn_tune_n = -1;   // topology calls: cloud size / dim / k the cached cell scale was measured for

@@ -1,5 +1,5 @@
 // wtp_ksel.hip — k-selection on the x-slowest halo layout (round 3): KNNTopology rows and the repel sweep with the
-// explicit k-selection (every force law), fp32 3-D clouds, k + self <= 22.
+// explicit k-selection (every force law), fp32 3-D clouds, k + self <= 24.
 //
 // What it computes is what brick_kernel<0,..> / brick_kernel<1,..,0> (wtp_brick.hip) compute —
 // `_build_knn_neighbors` (src/topology.jl:79-84) and the sweep closure of `_relax!` (src/repel.jl:256-292) with the
@@ -59,7 +59,7 @@ constexpr int kKsSU = 8;                                 // candidates per scan 
 constexpr int kKsPadBytes = 2 * kKsSU * 16;              // far sentinels behind the staged points
 constexpr int kKsMaxQ = 512;                             // queries per brick the lane table covers
 constexpr int kKsRing = 64;                              // hits per query = keys of the network
-constexpr int kKsKMax = 22;                              // largest k (self included where it is searched)
+constexpr int kKsKMax = 24;                              // largest k (self included where it is searched): the reference's 21 + self, + 2 candidates for the fp64 re-ranking
 constexpr int kKsRingLane = 68;                          // bytes of a lane's ring: 64 entries, 17 dwords apart (odd: the lanes of a wave start in 64 different banks)
 constexpr int kKsWaveBytes = 64 * kKsKMax * 4 + 256;     // per wave: the lanes' rings, later the wave's 64 rows (k ids each) + their row ids, written out together
 constexpr int kKsRingBytes = (kKsThreads / 64) * kKsWaveBytes;
@@ -756,6 +756,7 @@ template <int MODE, int KT> static int ksel_launch(wtp_ctx* ctx, SearchArgs<floa
 
 // KNNTopology rows (a.ksel_bx > 0: the caller built the grid for this layout); the caller cleared a.fb_count
 int launch_ksel_topology(wtp_ctx* ctx, SearchArgs<float>& a) {
+    if (a.k == 24) return ksel_launch<0, 24>(ctx, a); // fp64 KNNTopology at k = 21: k + self + 2 candidates for the exact re-ranking
     return a.k == 21 ? ksel_launch<0, 21>(ctx, a) : ksel_launch<0, 0>(ctx, a);
 }
 
