@@ -548,10 +548,18 @@ static int knn_dev_f64(wtp_ctx* ctx, const double* d_xyz, int64_t n, int dim, in
         a.cap_count = (float)ksel_cap_count(ctx, kc);
     }
     sp = span_begin(ctx, 1);
+    // k = 21 without self (kc = 24): search and re-ranking in slot order (see refine_f64_slots_kernel)
+    const bool slots = kc == 24 && !ctx->force_generic && getenv("WTP_F64_SLOTS_OFF") == nullptr;
+    double4* slot64 = (double4*)ctx->pts[1].p;
+    if (slots && (rc = launch_relabel_slots(ctx, raw64, sorted32, slot64, n))) return rc;
     rc = launch_topology<float>(ctx, a);
     if (rc) return rc;
-    rc = launch_refine_f64(ctx, raw64, a.idx_out, a.dist_out, n, kc, k, include_self, org4, d_idx, d_dist,
-                           (int32_t*)ctx->fb_list.p, (int32_t*)ctx->fb_count.p);
+    if (slots)
+        rc = launch_refine_f64_slots(ctx, slot64, a.idx_out, a.dist_out, n, kc, k, include_self, org4, d_idx, d_dist,
+                                     (int32_t*)ctx->fb_list.p, (int32_t*)ctx->fb_count.p);
+    else
+        rc = launch_refine_f64(ctx, raw64, a.idx_out, a.dist_out, n, kc, k, include_self, org4, d_idx, d_dist,
+                               (int32_t*)ctx->fb_list.p, (int32_t*)ctx->fb_count.p);
     span_end(ctx, sp);
     if (rc) return rc;
     ctx->n_sweep_launches += 1;

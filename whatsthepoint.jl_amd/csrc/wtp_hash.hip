@@ -608,6 +608,100 @@ __global__ void refine_f64_kernel(const double4* __restrict__ raw, const int32_t
     }
 }
 
+// Round 3: the same re-ranking in SLOT order.  The fp32 search ran on points relabelled with their slot in the sorted
+// array (relabel_slots_kernel), so its rows are in slot order and name slots: a query's candidates sit next to it in
+// `sorted` (the fp64 points in the same order) instead of anywhere in the input — the gathers hit the cache lines the
+// neighbouring queries just used — and the candidate list lives in registers (KC at compile time; the rows arrive in fp32
+// order, so exchange passes until nothing moves replace the insertion sort whose dynamically indexed arrays lived in scratch).
+// Canonical order and the row's place are by ORIGINAL id (kept in sorted[].w); failed queries are listed by original id.
+__global__ void relabel_slots_kernel(const double4* __restrict__ raw, float4* __restrict__ sorted32, double4* __restrict__ sorted64,
+                                     int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 p = sorted32[i];
+        sorted64[i] = raw[w_to_id(p.w)];
+        p.w = id_to_w(0.f, (int32_t)i);
+        sorted32[i] = p;
+    }
+}
+
+template <int KC>
+__global__ __launch_bounds__(128) void refine_f64_slots_kernel(const double4* __restrict__ sorted, const int32_t* __restrict__ cand,
+                                                               const float* __restrict__ cdist, int64_t n, int k, int include_self,
+                                                               const double* __restrict__ org4, int32_t* __restrict__ idx_out,
+                                                               double* __restrict__ dist_out, int32_t* __restrict__ fail_list,
+                                                               int32_t* __restrict__ fail_count) {
+    const double extent = org4[3];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double4 q = sorted[i];
+        const int32_t qid = w_to_id(q.w);
+        double kd[KC];
+        int32_t ki[KC];
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            const double4 p = sorted[cand[i * KC + j]];
+            kd[j] = dist2<double>(q.x, q.y, q.z, p.x, p.y, p.z);
+            ki[j] = w_to_id(p.w);
+        }
+        bool again = true;
+        while (again) { // (lane-local: the lists arrive almost sorted, one or two passes)
+            again = false;
+#pragma unroll
+            for (int j = 0; j + 1 < KC; ++j) {
+                const bool sw = lex_lt(kd[j + 1], ki[j + 1], kd[j], ki[j]);
+                const double td = kd[j];
+                const int32_t ti = ki[j];
+                kd[j] = sw ? kd[j + 1] : td;
+                ki[j] = sw ? ki[j + 1] : ti;
+                kd[j + 1] = sw ? td : kd[j + 1];
+                ki[j + 1] = sw ? ti : ki[j + 1];
+                again = again || sw;
+            }
+        }
+        const int kq = include_self ? k : k + 1;
+        const double dmax32 = (double)cdist[i * KC + KC - 1];
+        const double eps = extent * 0x1p-21 + dmax32 * 0x1p-20;
+        double dkq = kd[KC - 1];
+#pragma unroll
+        for (int j = 0; j < KC; ++j) dkq = (j == kq - 1) ? kd[j] : dkq;
+        const bool certified = (int64_t)KC >= n || wsqrt(dkq) < dmax32 - eps;
+        int out = 0;
+        int32_t* orow = idx_out + (int64_t)qid * k;
+        double* drow = dist_out ? dist_out + (int64_t)qid * k : nullptr;
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            const bool take = out < k && (include_self || ki[j] != qid); // self removed by index (src/topology.jl:82)
+            if (take) {
+                orow[out] = ki[j];
+                if (drow) drow[out] = wsqrt(kd[j]);
+                ++out;
+            }
+        }
+        if (!certified || out < k) {
+            const int pos = atomicAdd(fail_count, 1);
+            fail_list[pos] = qid;
+        }
+    }
+}
+
+int launch_relabel_slots(wtp_ctx* ctx, const double4* raw, float4* sorted32, double4* sorted64, int64_t n) {
+    hipLaunchKernelGGL(relabel_slots_kernel, dim3(grid_for(n, kThreads, 8192)), dim3(kThreads), 0, ctx->stream, raw, sorted32,
+                       sorted64, n);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
+// kc must be 24 (k = 21 without self, the reference's default) — the caller checks
+int launch_refine_f64_slots(wtp_ctx* ctx, const double4* sorted, const int32_t* cand, const float* cdist, int64_t n, int kc, int k,
+                            int include_self, const double* d_org4, int32_t* idx_out, double* dist_out, int32_t* fail_list,
+                            int32_t* fail_count) {
+    if (kc != 24) return fail(ctx, WTP_ERR_ARG, "launch_refine_f64_slots: kc must be 24");
+    WTP_HIP(ctx, hipMemsetAsync(fail_count, 0, sizeof(int32_t), ctx->stream));
+    hipLaunchKernelGGL(refine_f64_slots_kernel<24>, dim3(grid_for(n, 128, 16384)), dim3(128), 0, ctx->stream, sorted, cand, cdist, n,
+                       k, include_self, d_org4, idx_out, dist_out, fail_list, fail_count);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
 int launch_origin(wtp_ctx* ctx, const double4* pts, int64_t n, double* d_org4) {
     const int nbb = grid_for(n, kThreads, 1024);
     int rc;

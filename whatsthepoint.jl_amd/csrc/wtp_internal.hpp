@@ -423,6 +423,10 @@ int launch_to_local_f32(wtp_ctx* ctx, const double4* in, int64_t n, const double
 int launch_refine_f64(wtp_ctx* ctx, const double4* raw, const int32_t* cand, const float* cdist, int64_t n, int kc, int k,
                       int include_self, const double* d_org4, int32_t* idx_out, double* dist_out, int32_t* fail_list,
                       int32_t* fail_count);
+int launch_relabel_slots(wtp_ctx* ctx, const double4* raw, float4* sorted32, double4* sorted64, int64_t n);
+int launch_refine_f64_slots(wtp_ctx* ctx, const double4* sorted, const int32_t* cand, const float* cdist, int64_t n, int kc, int k,
+                            int include_self, const double* d_org4, int32_t* idx_out, double* dist_out, int32_t* fail_list,
+                            int32_t* fail_count);
 // isinside post-filter (wtp_inside.hip)
 int isinside_chunks(wtp_ctx* ctx, int64_t n, int64_t m, int points_per_block);
 int isinside_greens_ppb();
