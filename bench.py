@@ -125,6 +125,21 @@ def other_paths(ctx, torch, np, wtp_amd, extra_legs=False, e2e=True):
     out["knn_topology_k21_1M"] = {"value": round(n / dt / 1e6, 1), "unit": "Mpoints/s", "ms": round(dt * 1e3, 3),
                                   "alg_gbs": round(151.0 * n / dt / 1e9, 1),
                                   "note": "wtp_knn_dev: hash + ksel_kernel<0,21> (wtp_ksel.hip: x-slowest halo, hit masks, 64-key network), rows int32 on device"}
+    # the same cloud as Float64 (the reference's default type): fp32 candidate search in local coordinates + exact fp64 re-ranking
+    x64 = x.double()
+    for _ in range(2):
+        ctx.knn_dev(x64.data_ptr(), n, 3, np.float64, k, False, idx.data_ptr())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.knn_dev(x64.data_ptr(), n, 3, np.float64, k, False, idx.data_ptr())
+    torch.cuda.synchronize()
+    dt64 = (time.perf_counter() - t0) / reps
+    out["knn_topology_k21_1M_f64"] = {"value": round(n / dt64 / 1e6, 1), "unit": "Mpoints/s", "ms": round(dt64 * 1e3, 3),
+                                      "note": "wtp_knn_dev on a Float64 cloud: ksel_kernel<0,24> on the cloud rounded to float about its own "
+                                              "origin (k + self + 2 candidates), exact fp64 re-ranking in slot order with a per-query "
+                                              "certificate, exact fp64 wave path for what it does not certify"}
+    del x64
     xh = x.cpu().numpy()
     del x, idx
     r = (21.0 / (4.0 / 3.0 * np.pi * n)) ** (1.0 / 3.0)
