@@ -920,7 +920,7 @@ template <int MODE, int KT, int CS> static int brick_launch(wtp_ctx* ctx, Search
     return WTP_OK;
 }
 
-int brick_partials() { return 1024 + 8 + 512 + 512; } // bricks, then the follow-up and the ball kernel of the round-2 sweep (wtp_cs2.hip)
+int brick_partials() { return 1024 + 8 + 512 + 3072; } // bricks, then the follow-up and the ball kernel of the round-2 sweep (wtp_cs2.hip)
 
 // RadiusTopology through the brick kernel (fp32): rows of up to 32 entries are counted / sorted and written
 // here, the rest (longer rows, queries the 27 cells cannot certify, bricks too large for LDS) is appended

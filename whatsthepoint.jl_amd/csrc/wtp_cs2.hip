@@ -883,7 +883,7 @@ __global__ __launch_bounds__(kNnFixThreads, 8) void cs2_nnfix_kernel(SearchArgs<
 // What this kernel cannot certify either — more than k points in the ball, a coincident neighbour, a support wider
 // than four cells, an empty ball whose nearest neighbour the block does not certify — moves on to that path.
 constexpr int kBallThreads = 256;
-constexpr int kBallBlocksMax = 512;
+constexpr int kBallBlocksMax = 3072; // (512 left two thirds of the wave slots empty: the kernel is a chain of dependent loads per query, its rate is the number of queries in flight)
 constexpr int kBallRMax = 4;
 __global__ __launch_bounds__(kBallThreads, 6) void cs_ball_kernel(SearchArgs<float> a, const int32_t* __restrict__ list,
                                                                const int32_t* __restrict__ list_count,
