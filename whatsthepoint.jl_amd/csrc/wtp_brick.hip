@@ -980,6 +980,18 @@ template <> int launch_sweep<float>(wtp_ctx* ctx, SearchArgs<float>& a, bool fre
     // WTP_FULL_SELECT=1 asks for the explicit k-selection on every query (both give the same output)
     // (the caller sized the grid for it and says so by passing the LDS point capacity)
     const bool cs = a.brick_hcap > 0 && a.force_kind == WTP_FORCE_CLIPPED_SPACING && a.k >= 2 && !ctx->full_select;
+    if (cs && a.cs2_bx > 0 && a.spacing_pp && a.ball_list && !getenv("WTP_CS2_DEAD_OFF")) {
+        // variable spacing: bricks that would hand every point back are found first and passed over (wtp_cs2.hip)
+        const int dead_cap = (int)(ctx->cell_start.cap / sizeof(int32_t) / 4 + 4096);
+        int rd = ensure(ctx, ctx->brick_dead, (size_t)dead_cap);
+        if (!rd) rd = launch_cs2_dead(ctx, a, (uint8_t*)ctx->brick_dead.p, dead_cap);
+        if (rd) {
+            span_end(ctx, sp);
+            return rd;
+        }
+        a.brick_dead = (const uint8_t*)ctx->brick_dead.p;
+        a.brick_dead_cap = dead_cap;
+    }
     int rc = cs ? (a.cs2_bx > 0 ? launch_cs2(ctx, a) : brick_launch<1, 0, 1>(ctx, a))
                 : (a.k == 21 ? brick_launch<1, 21, 0>(ctx, a) : brick_launch<1, 0, 0>(ctx, a));
     span_end(ctx, sp);

@@ -181,7 +181,9 @@ __global__ __launch_bounds__(kCsThreads, 4) void cs2_kernel(SearchArgs<float> a,
     const bool const_ok = !a.spacing_pp && gmin > 0.f && lim_c <= gmin * gmin; // smallest provable radius covers the support
 
     // XCD-aware brick order (blocks sharing blockIdx % 8 share an L2): one contiguous slab of bricks each
-    const int groups = 8;
+    // (variable spacing: the live bricks of a graded cloud sit in a shell, so contiguous slabs per XCD would leave the XCDs
+    // that own the two z faces with twice the work of the others: the bricks are dealt out round-robin instead)
+    const int groups = a.brick_dead ? 1 : 8;
     const int per = (nbricks + groups - 1) / groups;
     const int xcd = blockIdx.x % groups;
     const int lane_blk = blockIdx.x / groups;
@@ -248,8 +250,19 @@ __global__ __launch_bounds__(kCsThreads, 4) void cs2_kernel(SearchArgs<float> a,
         }
     };
 
+    // variable spacing: bricks whose own points ALL ask for a support wider than any cell block certifies were listed for
+    // the ball kernel by cs2_dead_kernel; they are passed over here (no tables, no staging, no barriers)
+    auto skip_dead = [&](int& b, BrickPos& p) {
+        while (a.brick_dead && b < b_end && b < a.brick_dead_cap && a.brick_dead[b]) {
+            b += blk_per_group;
+            advance(p);
+        }
+    };
     int brick = xcd * per + lane_blk;
-    BrickPos pos = brick_pos(brick < nbricks ? brick : 0), pos_next = pos;
+    BrickPos pos = brick_pos(brick < nbricks ? brick : 0);
+    skip_dead(brick, pos);
+    BrickPos pos_next = pos;
+    int next = brick;
     int v[4] = {0, 0, 0, 0};
     float4 pv[4];
     pv[0] = pv[1] = pv[2] = pv[3] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -257,11 +270,12 @@ __global__ __launch_bounds__(kCsThreads, 4) void cs2_kernel(SearchArgs<float> a,
         load_cells(pos, v);
         load_points(v, pv);
     }
-    for (; brick < b_end; brick += blk_per_group, pos = pos_next) {
+    for (; brick < b_end; brick = next, pos = pos_next) {
         int bx, ox, oy, oz; // halo origin (cell coordinates)
         origin(pos, bx, ox, oy, oz);
-        const int next = brick + blk_per_group;
+        next = brick + blk_per_group;
         advance(pos_next);
+        skip_dead(next, pos_next);
 
         __builtin_amdgcn_s_setprio(0);
         __syncthreads(); // previous brick's LDS no longer in use
@@ -1017,6 +1031,59 @@ int launch_cs_ball(wtp_ctx* ctx, SearchArgs<float>& a, int32_t* rest_list, int32
     a.used_brick += blocks;
     a.fb_list = rest_list;
     a.fb_count = rest_count;
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
+}
+
+// Variable spacing (graded clouds): the cells follow the spacing of the DENSE part, so in the coarse bulk every point's
+// support is wider than the radius any 27-cell block certifies and the brick kernel would stage a brick (tables, halo,
+// four barriers) only to hand each of its two or three points back.  One thread per brick looks at the brick's own points
+// first: if every one is movable and asks for a support beyond (1.5 c)^2 — the largest radius a block certifies — the brick
+// is marked dead and its points go straight to the hand-back list (the ball kernel's input).  A dense brick is left at its
+// first point.  Graded 10 M points: 240 k of 300 k bricks are dead, cs2_kernel 3.4 -> see DESIGN.md.
+__global__ void cs2_dead_kernel(SearchArgs<float> a, int BX, uint8_t* __restrict__ dead, int dead_cap) {
+    if (a.stop && *a.stop) return;
+    const Grid<float> g = *a.grid;
+    const int nbx = (g.n[0] + BX - 1) / BX, nby = (g.n[1] + 1) / 2, nbz = (g.n[2] + 1) / 2;
+    const int nbricks = nbx * nby * nbz;
+    const float g2max = (1.5f * g.c) * (1.5f * g.c);
+    for (int brick = blockIdx.x * blockDim.x + threadIdx.x; brick < nbricks && brick < dead_cap; brick += gridDim.x * blockDim.x) {
+        const int bx = brick % nbx, by = (brick / nbx) % nby, bz = brick / (nbx * nby);
+        const int gx0 = bx * BX, gx1 = (gx0 + BX - 1) < g.n[0] - 1 ? (gx0 + BX - 1) : g.n[0] - 1;
+        int rs[4], re[4];
+        bool is_dead = true;
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int gy = by * 2 + (r4 & 1), gz = bz * 2 + (r4 >> 1);
+            rs[r4] = re[r4] = 0;
+            if (gy >= g.n[1] || gz >= g.n[2]) continue;
+            const int base = (gz * g.n[1] + gy) * g.n[0];
+            rs[r4] = a.cell_start[base + gx0];
+            re[r4] = a.cell_start[base + gx1 + 1];
+        }
+        for (int r4 = 0; r4 < 4 && is_dead; ++r4)
+            for (int i = rs[r4]; i < re[r4] && is_dead; ++i) {
+                const int32_t id = w_to_id(a.snap[i].w);
+                if (id < a.n_fixed) {
+                    is_dead = false;
+                } else {
+                    const float s = a.spacing_pp[id];
+                    is_dead = (a.u0 * a.u0) * (s * s) > g2max;
+                }
+            }
+        dead[brick] = is_dead ? 1 : 0;
+        if (is_dead) {
+            const int q = (re[0] - rs[0]) + (re[1] - rs[1]) + (re[2] - rs[2]) + (re[3] - rs[3]);
+            if (q > 0) {
+                int pos = atomicAdd(a.fb_count, q);
+                for (int r4 = 0; r4 < 4; ++r4)
+                    for (int i = rs[r4]; i < re[r4]; ++i) a.fb_list[pos++] = i;
+            }
+        }
+    }
+}
+
+int launch_cs2_dead(wtp_ctx* ctx, SearchArgs<float>& a, uint8_t* d_dead, int dead_cap) {
+    hipLaunchKernelGGL(cs2_dead_kernel, dim3(1024), dim3(256), 0, ctx->stream, a, a.cs2_bx, d_dead, dead_cap);
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;
 }

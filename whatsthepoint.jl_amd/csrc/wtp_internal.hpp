@@ -135,6 +135,8 @@ template <typename T> struct SearchArgs {
     T tnn_frac;                // CS sweeps: nearest-neighbour margin of the ring, in cell edges (WTP_TNN, default 0.8)
     int32_t brick_hcap;        // LDS point capacity for the brick kernel (0 = default)
     int32_t cs2_bx;            // > 0: brick length (own cells along x) of the round-2 compact-support sweep (wtp_cs2.hip)
+    const uint8_t* brick_dead; // wtp_cs2.hip, variable spacing: bricks whose points all went to the ball kernel's list already (cs2_dead_kernel), or nullptr
+    int32_t brick_dead_cap;
     int32_t counters_cleared;  // topology calls: the caller cleared fb_count / fb2_count (one 64-byte block) itself
     int32_t fb_r0;             // first block radius (cells) of the exact path for hand-backs; 0: the default (2: the 27 cells failed already)
     int32_t ksel_bx;           // > 0: the grid was built for the k-selection kernels of wtp_ksel.hip; largest brick length along x
@@ -253,6 +255,7 @@ struct wtp_ctx {
     wtp::DevBuf cand_idx, cand_dist, f32_pts; // fp64 topology: fp32 candidate lists and the float copy of the cloud
     wtp::DevBuf forces, nn_dist, nn_id, spacing_pp;
     wtp::DevBuf partials, stats, fb_list, fb_count, fb2_list, fb2_count, nn_list;
+    wtp::DevBuf brick_dead;    // wtp_cs2.hip, variable spacing: one byte per brick (cs2_dead_kernel)
     bool hash_scratch_clean = false;  // cell counts and dirty map are all-zero (every completed build leaves them so)
     bool counters_clean = false;      // the 64-byte counter block is all-zero (the step's final reduction leaves it so)
     wtp::DevBuf stop_state;           // wtp_relax_run_until: {stopped, reason, n_done, last_impr, best_cv} on the device
@@ -371,6 +374,7 @@ int launch_cs2_followup(wtp_ctx* ctx, SearchArgs<float>& a);
 int debug_kd_steps(unsigned long long out[2]); // -DWTP_DIAG builds: node visits / wave-walks of the spacing law's tree walk since the last call
 int launch_cs_ball(wtp_ctx* ctx, SearchArgs<float>& a, int32_t* rest_list, int32_t* rest_count);
 int launch_cs2_census(wtp_ctx* ctx, int BX, unsigned int* d_out513);
+int launch_cs2_dead(wtp_ctx* ctx, SearchArgs<float>& a, uint8_t* d_dead, int dead_cap);
 int cs2_max_bx();
 // wtp_ksel.hip: k-selection on the x-slowest layout (fp32, 3-D, k + self <= ksel_kmax())
 int launch_ksel_topology(wtp_ctx* ctx, SearchArgs<float>& a);
