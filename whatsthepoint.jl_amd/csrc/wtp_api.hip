@@ -1161,6 +1161,7 @@ static int cs2_tune(wtp_ctx* ctx, RelaxState& r, const Grid<float>& hg, double r
         int b = (int)(v + 0.5);
         return b < 2 ? (bx_max < 2 ? bx_max : 2) : (b > bx_max ? bx_max : b);
     };
+    r.cs2_rho = rho_est;
     int bx = clampbx(220.0 / (4.0 * rho_est));
     int q97 = 0, h999 = 0;
     for (int it = 0; it < 4; ++it) {
@@ -1403,6 +1404,7 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
     a.diag = (unsigned long long*)ctx->diag.p;
     a.brick_hcap = r.cs_sweep ? r.brick_hcap : (r.ksel_sweep ? r.ksel_hcap : 0);
     a.cs2_bx = r.cs_sweep ? r.cs2_bx : 0;
+    a.cs2_chunked = (r.spacing_kind != WTP_SPACING_CONSTANT || r.cs2_rho > 1.6) ? 1 : 0;
     a.ksel_bx = r.ksel_sweep ? r.ksel_bx : 0;
     if (r.ksel_sweep) a.cap_count = (float)ksel_cap_count(ctx, r.k);
     a.tnn_frac = (T)ctx->tnn_frac;

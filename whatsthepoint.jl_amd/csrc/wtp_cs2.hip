@@ -152,6 +152,10 @@ static size_t cs2_smem_bytes(int hcap) {
     return (size_t)hcap * 16 + kCsPadBytes + sizeof(Cs2Smem);
 }
 
+// CH: runs longer than the hit masks are taken in chunks (variable spacing, cells that hold several points).  The plain
+// variant gives such queries up, as round 3's first version did: it is the one the uniform headline runs, and the chunk loop
+// costs it two registers it does not have (128 VGPRs + 28 B of scratch: 0.572 -> 0.593 ms).
+template <bool CH>
 __global__ __launch_bounds__(kCsThreads, 4) void cs2_kernel(SearchArgs<float> a, int hcap, int BX) {
     if (a.stop && *a.stop) return; // wtp_relax_run_until: a stop rule fired earlier in this batch
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -451,16 +455,50 @@ __global__ __launch_bounds__(kCsThreads, 4) void cs2_kernel(SearchArgs<float> a,
             }
             // candidate run: halo cells P(hx-1, hz-1, hy-1) .. P(hx+1, hz+1, hy+1), contiguous in LDS
             const int Pf = (hx - 1) * kCsSlab + (hz - 1) * 4 + (hy - 1);
-            const uint32_t pa0 = (uint32_t)sm->ls[Pf] * 16u, ea = (uint32_t)sm->ls[Pf + kCsRun] * 16u;
+            const uint32_t pa_first = (uint32_t)sm->ls[Pf] * 16u, ea_all = (uint32_t)sm->ls[Pf + kCsRun] * 16u;
             // Hits are kept as a bit mask of the run's slots in three registers (96 slots = 12 steps; longer runs, a dense
             // cluster, give up): the scan loop then holds no LDS store at all.  Round 2 appended a byte per hit to a ring in
             // LDS — one ds_write_b8 (4 LDS cycles) next to every ds_read_b128 (4 + bank conflicts), which made the scan
             // LDS-bound: 4 waves x ~11 LDS cycles per candidate against 4 x ~10 VALU cycles on four SIMDs in parallel.
-            bool giveup = (ea - pa0) > (uint32_t)(kCsMaskSteps * kCsSU) * 16u;
-            const uint32_t ea_s = giveup ? pa0 : ea; // (a lane that gave up must not prolong the wave's loop: the masks hold 12 steps)
+            // Runs longer than the masks (cells that hold several points each: coarse grids of graded clouds, clusters) are taken
+            // in chunks of 96 slots — scan, then force pass, then the next chunk; the sums simply carry on.  Four chunks at most.
+            constexpr uint32_t kChunk = (uint32_t)(kCsMaskSteps * kCsSU) * 16u;
+            bool giveup = (ea_all - pa_first) > (CH ? 4u : 1u) * kChunk;
+            const uint32_t ea_all_s = giveup ? pa_first : ea_all; // (a lane that gave up must not prolong the wave's loops)
             const float tau_s = (cs_fail || giveup) ? -1.f : lim * (1.f + 0x1p-21f); // FMA filter, 4 ulp wide; the force pass is exact
             const uint32_t lds_base = (uint32_t)(uintptr_t)smem_raw;
-            uint32_t m0 = 0, m1 = 0, m2 = 0; // slot i of the run = bit (8 S - 1 - i) of m2:m1:m0 after S steps
+            // ---- force pass state: canonical d2 of every hit, exact cut, force sum (src/repel.jl:270-280) ----
+            const ForceCoefCs fc = force_coef_cs(a.beta, a.u0);
+            int n_oth = 0; // points other than the query inside the support (the query itself is always there)
+            bool coincident = false;
+            float Fx = 0.f, Fy = 0.f, Fz = 0.f;
+            int32_t nid = 0x7FFFFFFF;
+            float nd2 = Lim<float>::inf();
+            auto visit = [&](const float4& c) {
+                const float dx = qp.x - c.x, dy = qp.y - c.y, dz = qp.z - c.z;
+                const float d = (dx * dx + dy * dy) + dz * dz;
+                const int32_t cid = w_to_id(c.w);
+                const bool act = (d <= lim) & (cid != qid);
+                n_oth += act ? 1 : 0;
+                const bool nearer = act & ((d < nd2) | ((d == nd2) & (cid < nid)));
+                nd2 = nearer ? d : nd2;
+                nid = nearer ? cid : nid;
+                // f(u) / r with one reciprocal square root: (A - u2) / ((u2 + beta)^2 sqrt(d)) = (A - u2) rsq(d (u2 + beta)^4)
+                const float u2 = d * inv_s2, t = u2 + fc.beta, t2 = t * t;
+                const float r = __builtin_amdgcn_rsqf((d * t2) * t2);
+                const float f = fmaxf(fc.A - u2, 0.f) * r;
+                const bool pos = d > 0.f;
+                const float coef = (act & pos) ? f : 0.f;
+                Fx = __builtin_fmaf(coef, dx, Fx); // (this path's sum order differs from the reference's anyway)
+                Fy = __builtin_fmaf(coef, dy, Fy);
+                Fz = __builtin_fmaf(coef, dz, Fz);
+                coincident = coincident | (act & !pos);
+            };
+            for (uint32_t cbase = 0;; cbase += kChunk) { // wave-uniform trip count: one chunk for runs of up to 96 slots
+            const bool live = pa_first + cbase < ea_all_s;
+            const uint32_t pa0 = live ? pa_first + cbase : pa_first; // (a lane without slots in this chunk rereads its first ones, masked)
+            const uint32_t ea_s = live ? (ea_all_s < pa0 + kChunk ? ea_all_s : pa0 + kChunk) : pa0;
+            uint32_t m0 = 0, m1 = 0, m2 = 0; // slot i of the chunk = bit (8 S - 1 - i) of m2:m1:m0 after S steps
             CS_STAMP(1) // query setup
             if (WTP_DIAG) {
                 dt[9] += 1;                                           // query rounds (per wave)
@@ -541,7 +579,7 @@ __global__ __launch_bounds__(kCsThreads, 4) void cs2_kernel(SearchArgs<float> a,
             S = __builtin_amdgcn_readfirstlane(S);
             // the query's own bit: it is always set (d = 0), and skipping it here (src/repel.jl:271 skips self by index)
             // saves a trip of the force pass for the lanes with the most hits
-            if (!(cs_fail || giveup)) {
+            if (!(cs_fail || giveup) && qoff >= pa0 && ((qoff - pa0) >> 4) < (uint32_t)(8 * S)) { // (the query lies in this chunk)
                 const uint32_t bit = (uint32_t)(8 * S - 1) - ((qoff - pa0) >> 4);
                 const uint32_t one = 1u << (bit & 31u);
                 m0 &= bit < 32u ? ~one : ~0u;
@@ -550,35 +588,8 @@ __global__ __launch_bounds__(kCsThreads, 4) void cs2_kernel(SearchArgs<float> a,
             }
             CS_STAMP(2) // scan
 
-            // ---- force pass: canonical d2 of every hit, exact cut, force sum (src/repel.jl:270-280) ----
-            // Hits are taken off the mask words from the top (v_ffbh), two per trip; a lane whose word is empty reads its
-            // own point instead, which the self-exclusion by index (src/repel.jl:271) drops like the self hit itself.
-            const ForceCoefCs fc = force_coef_cs(a.beta, a.u0);
-            int n_oth = 0; // points other than the query inside the support (the query itself is always there)
-            bool coincident = false;
-            float Fx = 0.f, Fy = 0.f, Fz = 0.f;
-            int32_t nid = 0x7FFFFFFF;
-            float nd2 = Lim<float>::inf();
-            auto visit = [&](const float4& c) {
-                const float dx = qp.x - c.x, dy = qp.y - c.y, dz = qp.z - c.z;
-                const float d = (dx * dx + dy * dy) + dz * dz;
-                const int32_t cid = w_to_id(c.w);
-                const bool act = (d <= lim) & (cid != qid);
-                n_oth += act ? 1 : 0;
-                const bool nearer = act & ((d < nd2) | ((d == nd2) & (cid < nid)));
-                nd2 = nearer ? d : nd2;
-                nid = nearer ? cid : nid;
-                // f(u) / r with one reciprocal square root: (A - u2) / ((u2 + beta)^2 sqrt(d)) = (A - u2) rsq(d (u2 + beta)^4)
-                const float u2 = d * inv_s2, t = u2 + fc.beta, t2 = t * t;
-                const float r = __builtin_amdgcn_rsqf((d * t2) * t2);
-                const float f = fmaxf(fc.A - u2, 0.f) * r;
-                const bool pos = d > 0.f;
-                const float coef = (act & pos) ? f : 0.f;
-                Fx = __builtin_fmaf(coef, dx, Fx); // (this path's sum order differs from the reference's anyway)
-                Fy = __builtin_fmaf(coef, dy, Fy);
-                Fz = __builtin_fmaf(coef, dz, Fz);
-                coincident = coincident | (act & !pos);
-            };
+            // ---- force pass over this chunk's hits: taken off the mask words from the top (v_ffbh), two per trip; a lane whose
+            // word is empty reads its own point instead, which the self-exclusion by index (src/repel.jl:271) drops ----
             auto word_pass = [&](uint32_t mw, int top_slot) { // top_slot: the run slot of the word's bit 31
                 const uint32_t base_w = pa0 + (uint32_t)(top_slot * 16); // byte offset of that slot in the point area
                 while (__any(mw != 0u)) {
@@ -624,6 +635,8 @@ __global__ __launch_bounds__(kCsThreads, 4) void cs2_kernel(SearchArgs<float> a,
                     visit(c2);
                 }
             }
+            if (!CH || !__any(pa_first + cbase + kChunk < ea_all_s)) break;
+            } // chunks
             const int n_lim = n_oth + 1;
             CS_STAMP(3) // ring pass
             // not provable here: support wider than the certified radius, ring overflow, more than k points
@@ -656,8 +669,8 @@ __global__ __launch_bounds__(kCsThreads, 4) void cs2_kernel(SearchArgs<float> a,
                     const int pos = base_m + (int)__popcll(mm & ((1ull << lane) - 1ull));
                     if (pos < kCsMiss) {
                         CsMiss e;
-                        e.pa = pa0;
-                        e.ea = ea;
+                        e.pa = pa_first;
+                        e.ea = ea_all;
                         e.qoff = qoff;
                         e.gslot = gslot;
                         e.qid = qid;
@@ -890,8 +903,8 @@ __global__ __launch_bounds__(kNnFixThreads, 8) void cs2_nnfix_kernel(SearchArgs<
 // point asks for, the coarse part of a graded cloud asks for more) ------------------------------------------
 // The compact-support argument needs no brick: the ball of radius u0*s around the query, searched in the block of
 // (2R+1)^3 cells that provably contains it (R <= 4), holds n_lim <= k points -> they are the k-set's contributing
-// part and the sum over them is the reference's sum (src/repel.jl:270-280, src/repel_forces.jl:96-100).  Sixteen
-// lanes per query, four queries per wave, one x-row of the block per lane at a time; no LDS, so many waves are in
+// part and the sum over them is the reference's sum (src/repel.jl:270-280, src/repel_forces.jl:96-100).  Eight
+// lanes per query, eight queries per wave (round 3; sixteen / four before), one x-row of the block per lane at a time; no LDS, so many waves are in
 // flight and the chain of dependent loads (spacing, row bounds, points) overlaps across queries.  The exact
 // wave-per-query path took 7 ns for each of these (16 % of a 64x-graded cloud: 1.15 of 1.58 ms per iteration).
 // What this kernel cannot certify either — more than k points in the ball, a coincident neighbour, a support wider
@@ -899,6 +912,11 @@ __global__ __launch_bounds__(kNnFixThreads, 8) void cs2_nnfix_kernel(SearchArgs<
 constexpr int kBallThreads = 256;
 constexpr int kBallBlocksMax = 3072; // (512 left two thirds of the wave slots empty: the kernel is a chain of dependent loads per query, its rate is the number of queries in flight)
 constexpr int kBallRMax = 4;
+#ifndef WTP_BALL_LANES
+#define WTP_BALL_LANES 8 // (measured on the graded 10 M cloud, ms per iteration: 16 lanes 9.68, 8 lanes 9.10, 4 lanes 9.61)
+#endif
+constexpr int kBallLanes = WTP_BALL_LANES;          // lanes per query (a power of two)
+constexpr int kBallPerWave = 64 / kBallLanes;
 __global__ __launch_bounds__(kBallThreads, 6) void cs_ball_kernel(SearchArgs<float> a, const int32_t* __restrict__ list,
                                                                const int32_t* __restrict__ list_count,
                                                                int32_t* __restrict__ out_list, int32_t* __restrict__ out_count,
@@ -909,11 +927,11 @@ __global__ __launch_bounds__(kBallThreads, 6) void cs_ball_kernel(SearchArgs<flo
     const int n = *list_count;
     const int K = a.k;
     const int lane = threadIdx.x & 63;
-    const int grp = lane >> 4, l16 = lane & 15;
+    const int grp = lane / kBallLanes, l16 = lane % kBallLanes; // (l16: the lane's index inside its query's group)
     const int wave_g = (blockIdx.x * kBallThreads + threadIdx.x) >> 6, nwaves = (gridDim.x * kBallThreads) >> 6;
     const ForceCoefCs fc = force_coef_cs(a.beta, a.u0);
     Acc acc = acc_empty();
-    for (int i0 = wave_g * 4; i0 < n; i0 += nwaves * 4) {
+    for (int i0 = wave_g * kBallPerWave; i0 < n; i0 += nwaves * kBallPerWave) {
         const int i = i0 + grp;
         const bool on = i < n;
         const int gslot = list[on ? i : i0];
@@ -941,13 +959,13 @@ __global__ __launch_bounds__(kBallThreads, 6) void cs_ball_kernel(SearchArgs<flo
         float Fx = 0.f, Fy = 0.f, Fz = 0.f;
         int32_t nid = 0x7FFFFFFF;
         float nd2 = Lim<float>::inf();
-        // a lane's rows (at most six of the 81): all bounds first, then the points four loads at a time — the loop is a
+        // a lane's rows (at most eleven of the 81): all bounds first, then the points four loads at a time — the loop is a
         // chain of global round trips otherwise (one per point: 3.7 ns per query measured, 161 k queries 0.6 ms)
-        constexpr int kRowsPerLane = ((2 * kBallRMax + 1) * (2 * kBallRMax + 1) + 15) / 16;
+        constexpr int kRowsPerLane = ((2 * kBallRMax + 1) * (2 * kBallRMax + 1) + kBallLanes - 1) / kBallLanes;
         int ps[kRowsPerLane], pe[kRowsPerLane];
 #pragma unroll
         for (int j = 0; j < kRowsPerLane; ++j) {
-            const int row = l16 + 16 * j;
+            const int row = l16 + kBallLanes * j;
             const int y = cy + row % side - R, z = cz + row / side - R;
             const bool in = row < nrows && y >= 0 && y < g.n[1] && z >= 0 && z < g.n[2];
             const int base = in ? (z * g.n[1] + y) * g.n[0] : 0;
@@ -984,7 +1002,7 @@ __global__ __launch_bounds__(kBallThreads, 6) void cs_ball_kernel(SearchArgs<flo
         }
         // the sixteen lanes of the query: sums in a fixed order, lexicographic minimum
 #pragma unroll
-        for (int dlt = 8; dlt >= 1; dlt >>= 1) {
+        for (int dlt = kBallLanes / 2; dlt >= 1; dlt >>= 1) {
             Fx += __shfl_xor(Fx, dlt, 64);
             Fy += __shfl_xor(Fy, dlt, 64);
             Fz += __shfl_xor(Fz, dlt, 64);
@@ -1026,6 +1044,7 @@ __global__ __launch_bounds__(kBallThreads, 6) void cs_ball_kernel(SearchArgs<flo
 int launch_cs_ball(wtp_ctx* ctx, SearchArgs<float>& a, int32_t* rest_list, int32_t* rest_count) {
     int blocks = (int)((a.n + 1023) / 1024);
     blocks = blocks < 8 ? 8 : (blocks > kBallBlocksMax ? kBallBlocksMax : blocks);
+    if (const char* e = getenv("WTP_BALL_BLOCKS")) blocks = atoi(e) > 0 && atoi(e) <= kBallBlocksMax ? atoi(e) : blocks;
     hipLaunchKernelGGL(cs_ball_kernel, dim3(blocks), dim3(kBallThreads), 0, ctx->stream, a, (const int32_t*)a.fb_list,
                        (const int32_t*)a.fb_count, rest_list, rest_count, a.used_brick);
     a.used_brick += blocks;
@@ -1093,18 +1112,25 @@ int launch_cs2(wtp_ctx* ctx, SearchArgs<float>& a) {
     if (hcap < 64 || hcap > 4096 || BX < 1 || BX > kCsMaxBX)
         return fail(ctx, WTP_ERR_STATE, "compact-support sweep launched without a brick geometry");
     const size_t smem = cs2_smem_bytes(hcap);
-    if (ctx->cs2_smem != smem) { // per context: several contexts (devices) may coexist in one process
-        WTP_HIP(ctx, hipFuncSetAttribute((const void*)cs2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    const bool chunked = a.cs2_chunked != 0;
+    const void* fn = chunked ? (const void*)cs2_kernel<true> : (const void*)cs2_kernel<false>;
+    if (ctx->cs2_smem != smem || ctx->cs2_fn != fn) { // per context: several contexts (devices) may coexist in one process
+        WTP_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         int occ = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cs2_kernel, kCsThreads, smem);
+        hipError_t e = chunked ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cs2_kernel<true>, kCsThreads, smem)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, cs2_kernel<false>, kCsThreads, smem);
         if (e != hipSuccess || occ < 1) occ = 1;
         ctx->cs2_occ = occ > 4 ? 4 : occ;
         ctx->cs2_smem = smem;
+        ctx->cs2_fn = fn;
     }
     int gsz = ctx->sm_count * ctx->cs2_occ;
     gsz -= gsz % 8;
     if (gsz < 8) gsz = 8;
-    hipLaunchKernelGGL(cs2_kernel, dim3(gsz), dim3(kCsThreads), smem, ctx->stream, a, hcap, BX);
+    if (chunked)
+        hipLaunchKernelGGL(cs2_kernel<true>, dim3(gsz), dim3(kCsThreads), smem, ctx->stream, a, hcap, BX);
+    else
+        hipLaunchKernelGGL(cs2_kernel<false>, dim3(gsz), dim3(kCsThreads), smem, ctx->stream, a, hcap, BX);
     a.used_brick = gsz;
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;

@@ -137,6 +137,7 @@ template <typename T> struct SearchArgs {
     int32_t cs2_bx;            // > 0: brick length (own cells along x) of the round-2 compact-support sweep (wtp_cs2.hip)
     const uint8_t* brick_dead; // wtp_cs2.hip, variable spacing: bricks whose points all went to the ball kernel's list already (cs2_dead_kernel), or nullptr
     int32_t brick_dead_cap;
+    int32_t cs2_chunked;       // wtp_cs2.hip: runs longer than the hit masks are taken in chunks (variable spacing, several points per cell)
     int32_t counters_cleared;  // topology calls: the caller cleared fb_count / fb2_count (one 64-byte block) itself
     int32_t fb_r0;             // first block radius (cells) of the exact path for hand-backs; 0: the default (2: the 27 cells failed already)
     int32_t ksel_bx;           // > 0: the grid was built for the k-selection kernels of wtp_ksel.hip; largest brick length along x
@@ -185,6 +186,7 @@ struct RelaxState {
     bool ksel_sweep = false; // k-selection sweep on the x-slowest layout (wtp_ksel.hip)
     int ksel_bx = 0, ksel_hcap = 0; // its brick length along x and LDS point area, measured with the grid
     double ksel_rho = 0;     // the occupancy picked for this cloud (ksel_pick_rho)
+    double cs2_rho = 0;      // points per cell the sweep's bricks were sized for (cs2_tune)
     int cs2_bx = 0;          // > 0: the round-2 compact-support sweep (wtp_cs2.hip) with bricks of this many cells along x
     int64_t tuned_fixed = 0; // fixed points the grid / brick geometry was measured with (a swapped head re-measures when it differs by > 5 % of n)
     double sp_p0 = 0, sp_p1 = 0, sp_p2 = 0; // LOGLIKE / BOUNDARY_LAYER parameters
@@ -223,6 +225,7 @@ struct wtp_ctx {
     double rho_ksel = 1.2;     // WTP_RHO_KSEL: points per cell of the wtp_ksel.hip grids at k + self = 22 (scales with k)
     double cap_ksel = 40.0;    // WTP_CAP_KSEL: points the first filter ball of wtp_ksel.hip is expected to hold at k + self = 22
     size_t cs2_smem = 0;       // launch attributes of cs2_kernel cached per context
+    const void* cs2_fn = nullptr; // (and the variant they belong to)
     int cs2_occ = 0;
     // (kernel, dynamic LDS bytes) -> blocks per CU, per CONTEXT: the dynamic-LDS attribute and the occupancy are
     // properties of a kernel on one device, and several contexts (devices) may live in one process
