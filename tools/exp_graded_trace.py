@@ -7,16 +7,17 @@ import wtp_amd as w
 ctx = w.Context(0)
 force = dict(kind=2, beta=0.2, u0=1.0, gamma=3.0)
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000
-x = w.synth.graded(n, 4.0, 0.2, np.float32)
+dt = np.float64 if os.environ.get("DT") == "f64" else np.float32
+x = w.synth.graded(n, 4.0, 0.2, dt)
 shell = (np.minimum(x, 1 - x).min(axis=1) < 0.02).sum()
 hw = ((1 - 0.96 ** 3) / shell) ** (1 / 3)
 m = max(int(1 / hw), 8)
-g = (np.arange(m, dtype=np.float32) + 0.5) / m
+g = (np.arange(m, dtype=dt) + 0.5) / m
 u, v = np.meshgrid(g, g, indexing="ij")
 faces = []
 for axis in range(3):
     for side in (0.0, 1.0):
-        c = np.zeros((m * m, 3), np.float32); c[:, axis] = side
+        c = np.zeros((m * m, 3), dt); c[:, axis] = side
         c[:, (axis + 1) % 3] = u.ravel(); c[:, (axis + 2) % 3] = v.ravel(); faces.append(c)
 b = np.concatenate(faces)
 law = w.BoundaryLayerSpacing(b, at_wall=hw, bulk=4 * hw, layer_thickness=0.2)
