@@ -53,8 +53,8 @@ def test_knn_on_graded_cloud_matches_oracle(O, wtp, ctx, dtype):
     assert np.array_equal(idx, widx) and np.array_equal(dist, wdist)
 
 
-def test_sweep_on_graded_cloud_with_its_spacing_law(O, wtp, ctx):
-    n = 60_000
+@pytest.mark.parametrize("n", [60_000, 300_000])   # the larger one: dead bricks passed over, runs taken in chunks, ball kernel
+def test_sweep_on_graded_cloud_with_its_spacing_law(O, wtp, ctx, n):
     x = wtp.synth.graded(n, 4.0, 0.2, np.float32)
     shell = (np.minimum(x, 1 - x).min(axis=1) < 0.02).sum()
     hw = float(((1 - 0.96 ** 3) / shell) ** (1 / 3))
