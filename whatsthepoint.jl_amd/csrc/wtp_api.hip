@@ -369,7 +369,7 @@ static int knn_dev_t(wtp_ctx* ctx, const T* d_xyz, int64_t n, int dim, int k, in
     // The measured cell scale of the last topology call is reused for a cloud of the same size (the
     // usual case: rebuild_topology! on the same points); it only affects speed, never the result.
     const int kq = include_self ? k : k + 1;
-    // fp32 3-D clouds with k + self <= 22 (the reference's k = 21 among them): the x-slowest layout of wtp_ksel.hip —
+    // fp32 3-D clouds with k + self <= 24 (the reference's k = 21 among them): the x-slowest layout of wtp_ksel.hip —
     // cells of ~1.2 points, the k nearest inside the 5 x 5 x 5 block around the query's cell
     const bool ksel = sizeof(T) == 4 && dim == 3 && ctx->ksel && !ctx->force_generic && kq <= ksel_kmax() && n >= 4096;
     const double rho_direct = ksel ? ksel_rho_for(ctx, kq) : 0.0;
