@@ -1,4 +1,4 @@
-"""GPU parity of the k-selection kernels on the x-slowest layout (wtp_ksel.hip: fp32, 3-D, k + self <= 22, n >= 4096)
+"""GPU parity of the k-selection kernels on the x-slowest layout (wtp_ksel.hip: fp32, 3-D, k + self <= 24, n >= 4096)
 against the CPU oracle and against the 4 x 4 x 4-brick kernels they replace (WTP_KSEL=0).  Bar: neighbour rows and
 distances bit-exact; repelled coordinates within 2e-5 spacings after one sweep (the summation order differs)."""
 import os
@@ -15,7 +15,8 @@ def _sweep_args(n):
 
 
 @pytest.mark.parametrize("n,k,inc", [(4096, 1, False), (5000, 5, False), (20000, 21, False), (20000, 22, True),
-                                     (20000, 21, True), (30000, 12, False), (100000, 21, False)])
+                                     (20000, 21, True), (30000, 12, False), (100000, 21, False), (40000, 23, False),
+                                     (40000, 24, True), (40000, 24, False)])  # (the last: k + self = 25, the brick kernels)
 def test_ksel_knn_matches_oracle(ctx, O, wtp, n, k, inc):
     x = wtp.synth.uniform(n, 3, np.float32, 20260821 + n)
     idx, dist = ctx.knn(x, k, include_self=inc, return_dist=True)
@@ -60,7 +61,7 @@ def test_ksel_equals_brick_kernels(wtp):
 
 
 @pytest.mark.parametrize("kind,beta,u0,gamma,k,n_fixed", [(0, 0.2, 1.0, 3.0, 21, 0), (1, 0.2, 1.0, 3.0, 21, 3000),
-                                                          (3, 0.2, 1.0, 3.0, 12, 0), (3, 0.3, 1.0, 2.0, 22, 0)])
+                                                          (3, 0.2, 1.0, 3.0, 12, 0), (3, 0.3, 1.0, 2.0, 22, 0), (0, 0.2, 1.0, 3.0, 24, 0)])
 def test_ksel_sweep_force_models(ctx, O, wtp, kind, beta, u0, gamma, k, n_fixed):
     n = 30000
     x = wtp.synth.uniform(n, 3, np.float32, 20260821)
