@@ -680,7 +680,7 @@ WTP_API int wtp_destroy(wtp_ctx* ctx) {
                       &ctx->cell_cnt, &ctx->cell_start, &ctx->scan_tmp, &ctx->grid, &ctx->bbox_part,
                       &ctx->idx_out, &ctx->dist_out, &ctx->counts_out, &ctx->forces, &ctx->nn_dist,
                       &ctx->nn_id, &ctx->spacing_pp, &ctx->partials, &ctx->stats, &ctx->fb_list,
-                      &ctx->fb_count, &ctx->fb2_list, &ctx->fb2_count, &ctx->nn_list, &ctx->brick_dead, &ctx->scratch, &ctx->diag,
+                      &ctx->fb_count, &ctx->fb2_list, &ctx->fb2_count, &ctx->nn_list, &ctx->brick_dead, &ctx->rad_tmp, &ctx->rad_done, &ctx->rad_arena, &ctx->rad_arena_off, &ctx->scratch, &ctx->diag,
                       &ctx->ins_in, &ctx->ins_elems, &ctx->ins_partial, &ctx->ins_out, &ctx->mesh_nodes, &ctx->mesh_pn, &ctx->mesh_io,
                       &ctx->wall_flags, &ctx->wall_tri, &ctx->wall_hint, &ctx->mesh_cls, &ctx->kd_nodes, &ctx->sp_hint, &ctx->occ, &ctx->box_dev,
                       &ctx->cand_idx, &ctx->cand_dist, &ctx->f32_pts, &ctx->comm_scratch, &ctx->sp_cert};
@@ -853,6 +853,33 @@ template <typename T> static int radius_count_t(wtp_ctx* ctx, int64_t n, int dim
     ctx->counters_clean = false; // (this call counts in the block; the next sweep clears it itself)
     a.fb_list = (int32_t*)ctx->fb_list.p; // queries the brick kernel hands back to the wave kernel
     a.fb_count = (int32_t*)ctx->fb_count.p;
+    // fp32: the brick kernel parks the rows it finds (32 ids per query) and marks the query, so that wtp_radius_fill copies
+    // them instead of running the whole search a second time (128 B per point of scratch; WTP_RADIUS_CACHE=0 switches it off)
+    ctx->rad_rows_cached = false;
+    if (ctx->force_generic != 2 && !(getenv("WTP_RADIUS_CACHE") && atoi(getenv("WTP_RADIUS_CACHE")) == 0)) {
+        if ((rc = ensure(ctx, ctx->rad_done, (size_t)n + 64))) return rc;
+        WTP_HIP(ctx, hipMemsetAsync(ctx->rad_done.p, 0, (size_t)n, ctx->stream));
+        a.rad_done = (uint8_t*)ctx->rad_done.p;
+        if (sizeof(T) == 4 && !ctx->force_generic) { // the brick kernel's rows: 32 ids per query
+            if ((rc = ensure(ctx, ctx->rad_tmp, sizeof(int32_t) * 32 * (size_t)n))) return rc;
+            a.rad_tmp = (int32_t*)ctx->rad_tmp.p;
+        }
+        // the wave kernel's rows (any length up to its list), where it serves every query (fp64; fp32 grids whose rows are
+        // expected to outgrow the brick kernel, Grid::rad_wave_only; WTP_FORCE_GENERIC=1): an arena of 48 ids per point,
+        // shared out evenly among the waves; a row that does not fit any more is simply searched again by the fill phase.
+        // (For the hand-backs of the fp32 brick kernel it buys nothing: measured 2.07 -> 2.14 ms per graded 1 M cloud —
+        // ranking in the count phase costs what it saves in the fill phase; the kernel decides by the grid's flag.)
+        {
+            const int64_t arena_cap = 48 * n;
+            if ((rc = ensure(ctx, ctx->rad_arena, sizeof(int32_t) * (size_t)arena_cap))) return rc;
+            if ((rc = ensure(ctx, ctx->rad_arena_off, sizeof(int64_t) * (size_t)(n + 2)))) return rc;
+            a.rad_arena = (int32_t*)ctx->rad_arena.p;
+            a.rad_arena_off = (int64_t*)ctx->rad_arena_off.p;
+            a.rad_arena_pos = nullptr;
+            a.rad_arena_cap = arena_cap;
+        }
+        ctx->rad_rows_cached = true;
+    }
     sp = span_begin(ctx, 1);
     rc = launch_radius_count<T>(ctx, a, (T)r, d_counts);
     span_end(ctx, sp);
@@ -870,6 +897,15 @@ template <typename T> static int radius_fill_t(wtp_ctx* ctx, const int64_t* d_of
     a.fb2_count = (int32_t*)ctx->fb2_count.p;
     a.fb_list = (int32_t*)ctx->fb_list.p; // ensured by the count phase
     a.fb_count = (int32_t*)ctx->fb_count.p;
+    if (ctx->rad_rows_cached) { // (set by the count phase of this very cloud: rad_valid guards the pair of calls)
+        a.rad_tmp = sizeof(T) == 4 && !ctx->force_generic ? (int32_t*)ctx->rad_tmp.p : nullptr;
+        a.rad_done = (uint8_t*)ctx->rad_done.p;
+        {
+            a.rad_arena = (int32_t*)ctx->rad_arena.p;
+            a.rad_arena_off = (int64_t*)ctx->rad_arena_off.p;
+            a.rad_arena_cap = 48 * ctx->rad_n;
+        }
+    }
     int sp = span_begin(ctx, 1);
     int rc = launch_radius_fill<T>(ctx, a, (T)ctx->rad_r, d_off, d_idx);
     span_end(ctx, sp);

@@ -276,6 +276,7 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
     uint16_t* ring = ring_all + tid; // entry j at ring[j * kBrickThreads]; row nb is a dump row
 
     const Grid<float> g = *a.grid;
+    if (MODE == 2 && g.rad_wave_only) return; // rows expected to outgrow this kernel's 32 entries: the wave kernel takes every query (grid_setup_kernel)
     const int K = KT > 0 ? KT : a.k;
     const bool skip_self = (MODE == 0 && !a.include_self) || MODE == 2; // radius rows never hold the point itself (src/topology.jl:96)
     const float cap2 = (a.gamma_cap * g.c) * (a.gamma_cap * g.c);
@@ -342,7 +343,10 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
         }
         __syncthreads();
         const int halo_total = sm->hstart[HCELLS];
-        const bool overflow = halo_total > hcap;
+        // RadiusTopology: a brick whose cells hold more than ~7.4 points has rows beyond this kernel's 32 entries (a row is
+        // ~4.06 cells' worth of points); it is handed to the wave kernel up front, like a brick that does not fit LDS,
+        // instead of being staged and scanned first (the dense part of a graded cloud)
+        const bool overflow = halo_total > hcap || (MODE == 2 && halo_total > 1600);
 
         // ---- 2. own-row prefix (queries = points of the BX*BY*BZ own cells) ------------------
         if (tid == 0) {
@@ -757,9 +761,10 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
             if (MODE == 2) fallback = giveup || rad_fail || cnt > 32; // longer rows: the wave kernel's LDS list
             if (MODE == 2) {
                 if (!fallback) {
-                    if (!a.rad_fill) {
-                        a.rad_counts[qid] = cnt; // first phase of the CSR: row lengths
-                    } else {
+                    if (!a.rad_fill) a.rad_counts[qid] = cnt; // first phase of the CSR: row lengths
+                    if (a.rad_fill || a.rad_tmp) {
+                        // the row in canonical (d2, id) order: written to its place in the CSR (fill phase), or parked in the
+                        // count phase already so that the fill phase is a copy and not a second search (a.rad_tmp)
                         uint64_t k[32];
 #pragma unroll
                         for (int j = 0; j < 32; ++j) {
@@ -768,10 +773,11 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
                             k[j] = j < cnt ? (((uint64_t)d << 32) | (uint32_t)w_to_id(c.w)) : ~0ull;
                         }
                         WTP_SORTNET_32(k)
-                        int32_t* orow = a.idx_out + a.rad_offsets[qid];
+                        int32_t* orow = a.rad_fill ? a.idx_out + a.rad_offsets[qid] : a.rad_tmp + (int64_t)qid * 32;
 #pragma unroll
                         for (int j = 0; j < 32; ++j)
                             if (j < cnt) orow[j] = (int32_t)(uint32_t)k[j];
+                        if (!a.rad_fill) a.rad_done[qid] = 1;
                     }
                 }
             } else if (MODE == 0) {

@@ -242,6 +242,30 @@ template <> bool brick_radius_usable<float>(wtp_ctx* ctx, SearchArgs<float>& a) 
 template <typename T> static int brick_radius(wtp_ctx*, SearchArgs<T>&) { return WTP_OK; }
 template <> int brick_radius<float>(wtp_ctx* ctx, SearchArgs<float>& a) { return launch_brick_radius(ctx, a); }
 
+// Fill phase when the count phase parked the brick kernel's rows: one thread per query copies its row (at most 32 ids,
+// already in canonical order) to its place in the CSR; queries the brick kernel handed back are filled by the wave kernel.
+__global__ void radius_copy_rows_kernel(int64_t n, const int32_t* __restrict__ tmp, const uint8_t* __restrict__ done,
+                                        const int32_t* __restrict__ arena, const int64_t* __restrict__ arena_off,
+                                        const int64_t* __restrict__ offsets, int32_t* __restrict__ idx) {
+    // sixteen lanes per row: rows of the wave kernel's arena run to hundreds of ids
+    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4, ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    const int l = threadIdx.x & 15;
+    for (int64_t q = grp; q < n; q += ngrp) {
+        const uint8_t d = done[q];
+        if (!d) continue;
+        const int64_t o = offsets[q];
+        int64_t len = offsets[q + 1] - o;
+        const int32_t* row;
+        if (d == 1) {
+            row = tmp + q * 32;
+            len = len > 32 ? 32 : len;
+        } else {
+            row = arena + arena_off[q];
+        }
+        for (int64_t j = l; j < len; j += 16) idx[o + j] = row[j];
+    }
+}
+
 template <typename T>
 int launch_radius_count(wtp_ctx* ctx, SearchArgs<T>& a, T r, int32_t* d_counts) {
     if (ctx->force_generic == 2) {
@@ -277,7 +301,18 @@ int launch_radius_fill(wtp_ctx* ctx, SearchArgs<T>& a, T r, const int64_t* d_off
     }
     WTP_HIP(ctx, hipMemsetAsync(a.fb2_count, 0, sizeof(int32_t), ctx->stream));
     int rc;
-    if (brick_radius_usable<T>(ctx, a)) {
+    if (a.rad_done && (a.rad_arena || (brick_radius_usable<T>(ctx, a) && a.rad_tmp))) {
+        // the count phase parked the rows it found: copy them.  What it could not park (arena full, rows beyond the wave
+        // kernel's list) is searched again: by the wave kernel over the brick kernel's hand-back list, which still stands
+        // (fp32), or over all points (it skips the parked ones), then by the serial kernel
+        hipLaunchKernelGGL(radius_copy_rows_kernel, dim3(blocks_for((int64_t)a.n * 16, 16384)), dim3(kThreads), 0, ctx->stream,
+                           (int64_t)a.n, (const int32_t*)a.rad_tmp, (const uint8_t*)a.rad_done, (const int32_t*)a.rad_arena,
+                           (const int64_t*)a.rad_arena_off, d_offsets, d_idx);
+        if (brick_radius_usable<T>(ctx, a) && a.rad_tmp)
+            rc = launch_wave_radius_fill<T>(ctx, a, r, d_offsets, d_idx, a.fb_list, a.fb_count);
+        else
+            rc = launch_wave_radius_fill<T>(ctx, a, r, d_offsets, d_idx, nullptr, nullptr);
+    } else if (brick_radius_usable<T>(ctx, a)) {
         WTP_HIP(ctx, hipMemsetAsync(a.fb_count, 0, sizeof(int32_t), ctx->stream));
         a.radius2 = r * r;
         a.rad_counts = nullptr;

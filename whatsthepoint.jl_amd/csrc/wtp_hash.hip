@@ -166,6 +166,18 @@ __global__ void grid_setup_kernel(const T* __restrict__ part, int nparts, Grid<T
     g->nbricks = g->nb[0] * g->nb[1] * g->nb[2];
     g->dim = dim;
     g->npts = (int32_t)npts;
+    // RadiusTopology: expected row length at the box-average density.  Rows beyond 32 entries are handed back by the brick
+    // kernel one by one after it has staged and scanned them; past ~30 expected neighbours (a graded cloud's average of 40
+    // hides a dense part at 65) the wave kernel alone is faster (measured at 1 M points: 20.6 per row 0.64 vs 1.40 ms,
+    // 40 graded 2.07 vs 1.82, 68.9 per row 3.07 vs 2.64)
+    g->rad_wave_only = 0;
+    if (radius > 0 && emax > 0) {
+        double vol = 1.0;
+        for (int a = 0; a < dim; ++a) vol *= (ext[a] > emax * 1e-6 ? ext[a] : emax * 1e-6);
+        const double ball = dim == 3 ? 4.18879 * radius * radius * radius : 3.14159265 * radius * radius;
+        g->rad_wave_only = (double)npts / vol * ball > 30.0 ? 1 : 0;
+    }
+    g->pad_ = 0;
 }
 
 template <typename T>

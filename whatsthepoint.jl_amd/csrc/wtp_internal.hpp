@@ -48,6 +48,8 @@ template <typename T> struct Grid {
     int32_t nbricks;
     int32_t dim;
     int32_t npts;
+    int32_t rad_wave_only; // RadiusTopology builds: rows are expected to outgrow the brick kernel's 32 entries — the wave kernel serves every query
+    int32_t pad_;
 };
 
 constexpr int kMaxAxisCells = 4096;
@@ -113,6 +115,12 @@ template <typename T> struct SearchArgs {
     int32_t* rad_counts;
     const int64_t* rad_offsets;
     int32_t rad_fill;
+    int32_t* rad_tmp;          // count phase, fp32 brick kernel: the sorted row of every query it serves (32 ids each) is parked here,
+    uint8_t* rad_done;         // and the query marked (1), so that the fill phase copies rows instead of searching again (or nullptr)
+    int32_t* rad_arena;        // count phase, wave kernel: ranked rows of any length, bump-allocated (mark 2, start in rad_arena_off)
+    int64_t* rad_arena_off;
+    unsigned long long* rad_arena_pos;
+    int64_t rad_arena_cap;
     // fallback work list
     int32_t* fb_list;
     int32_t* fb_count;
@@ -258,6 +266,8 @@ struct wtp_ctx {
     wtp::DevBuf cand_idx, cand_dist, f32_pts; // fp64 topology: fp32 candidate lists and the float copy of the cloud
     wtp::DevBuf forces, nn_dist, nn_id, spacing_pp;
     wtp::DevBuf partials, stats, fb_list, fb_count, fb2_list, fb2_count, nn_list;
+    wtp::DevBuf rad_tmp, rad_done; // RadiusTopology: rows parked by the count phase (32 ids per query), one byte per query
+    wtp::DevBuf rad_arena, rad_arena_off; // ... and the wave kernel's rows (any length), their starts; the bump counter sits behind the starts
     wtp::DevBuf brick_dead;    // wtp_cs2.hip, variable spacing: one byte per brick (cs2_dead_kernel)
     bool hash_scratch_clean = false;  // cell counts and dirty map are all-zero (every completed build leaves them so)
     bool counters_clean = false;      // the 64-byte counter block is all-zero (the step's final reduction leaves it so)
@@ -299,6 +309,7 @@ struct wtp_ctx {
     double rad_r = 0;
     int64_t rad_nnz = 0;
     bool rad_valid = false;
+    bool rad_rows_cached = false; // the count phase parked the brick kernel's rows (rad_tmp / rad_done): the fill phase copies them
     bool rad_offsets_dev = false; // wtp_radius_offsets left the CSR offsets in dist_out (device): fill may take them from there
     wtp::RelaxState relax;
     // timers

@@ -397,12 +397,17 @@ __global__ __launch_bounds__(kThreads) void wave_radius_kernel(SearchArgs<T> a, 
     const T r2 = r * r; // inclusive, compared as d2 <= r*r
     const int wave_global = blockIdx.x * kWaves + wave;
     const int wave_stride = gridDim.x * kWaves;
-    const int nq = list ? *list_count : a.n; // list: the queries the brick kernel handed back
+    // list: the queries the brick kernel handed back — unless the grid says that kernel stood aside (rad_wave_only)
+    const bool all = !list || g.rad_wave_only;
+    const int nq = all ? a.n : *list_count;
     const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    int64_t arena_used = 0; // ids this wave has parked in its share of the arena (count phase with ranking)
     for (int qi = wave_global; qi < nq; qi += wave_stride) {
-        const int slot = list ? list[qi] : qi;
+        const int slot = all ? qi : list[qi];
         const Pt<T> q = a.snap[slot];
         const int32_t id = w_to_id(q.w);
+        // fill phase proper (counts == nullptr): a row the count phase ranked and parked in the arena is copied, not searched again
+        if (FILL && !counts && a.rad_done && a.rad_done[id] == 2) continue;
         const int cx = cell_coord(g, q.x, 0), cy = cell_coord(g, q.y, 1), cz = cell_coord(g, q.z, 2);
         const int z0 = cz - 1 < 0 ? 0 : cz - 1, z1 = cz + 1 > g.n[2] - 1 ? g.n[2] - 1 : cz + 1;
         const int y0 = cy - 1 < 0 ? 0 : cy - 1, y1 = cy + 1 > g.n[1] - 1 ? g.n[1] - 1 : cy + 1;
@@ -464,16 +469,39 @@ __global__ __launch_bounds__(kThreads) void wave_radius_kernel(SearchArgs<T> a, 
             if (lane == 0) counts[id] = m;
             continue;
         }
-        if (m > kRadCap) { // row longer than the LDS list: serial kernel
-            if (lane == 0) {
+        // FILL with `counts`: the COUNT phase run with ranking — the row goes to a bump-allocated arena (its length to counts),
+        // the fill phase then copies it (radius_copy_rows_kernel) instead of searching and ranking a second time
+        // (only where this kernel serves every query: for the brick kernel's hand-backs ranking in the count phase costs what
+        // it saves in the fill phase)
+        const bool arena = counts != nullptr && all && a.rad_arena != nullptr;
+        if (counts && lane == 0) counts[id] = m;
+        if (counts && !arena) continue; // count phase, plain
+        if (m > kRadCap) { // row longer than the LDS list: serial kernel (from the fill phase proper)
+            if (!arena && lane == 0) {
                 const int pos = atomicAdd(a.fb2_count, 1);
                 a.fb2_list[pos] = slot;
             }
             continue;
         }
         __builtin_amdgcn_wave_barrier();
-        const int64_t base = offsets[id];
-        const int64_t cap = offsets[id + 1] - base;
+        int64_t base, cap;
+        if (arena) {
+            // every wave owns an equal share of the arena and fills it from the front (its queries are strided over the list,
+            // so the shares fill evenly): no atomic — one counter for a million rows serialises the whole kernel
+            const int64_t share = a.rad_arena_cap / wave_stride;
+            if (arena_used + m > share) continue; // share full: the fill phase searches this row again
+            base = (int64_t)wave_global * share + arena_used;
+            arena_used += m;
+            cap = m;
+            idx_out = a.rad_arena;
+            if (lane == 0) {
+                a.rad_arena_off[id] = base;
+                a.rad_done[id] = 2;
+            }
+        } else {
+            base = offsets[id];
+            cap = offsets[id + 1] - base;
+        }
         if constexpr (sizeof(T) == 4) {
             // every lane ranks the (up to four) entries it owns against all m keys, two keys per LDS read
             if (lane == 0) sm->key[m] = ~0ull; // an odd m reads one key past the end
@@ -517,8 +545,12 @@ int launch_wave_radius_count(wtp_ctx* ctx, SearchArgs<T>& a, T r, int32_t* d_cou
                              const int32_t* list_count) {
     int64_t want = ((int64_t)a.n / (list ? 16 : 1) + kWaves - 1) / kWaves;
     int nb = (int)(want > 16384 ? 16384 : (want < 64 ? 64 : want));
-    hipLaunchKernelGGL((wave_radius_kernel<T, false>), dim3(nb), dim3(kThreads), 0, ctx->stream, a, r,
-                       d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, list, list_count);
+    if (a.rad_arena && a.rad_done && !list) // count WITH ranking where this kernel serves every query by construction: rows parked for the fill phase
+        hipLaunchKernelGGL((wave_radius_kernel<T, true>), dim3(nb), dim3(kThreads), 0, ctx->stream, a, r, d_counts,
+                           (const int64_t*)nullptr, (int32_t*)nullptr, list, list_count);
+    else
+        hipLaunchKernelGGL((wave_radius_kernel<T, false>), dim3(nb), dim3(kThreads), 0, ctx->stream, a, r,
+                           d_counts, (const int64_t*)nullptr, (int32_t*)nullptr, list, list_count);
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;
 }
