@@ -12,10 +12,11 @@
 //     5 x 5 x 5 block of a query is then ONE contiguous run of 173 halo cells (its 125 plus 48 cells three rows away in
 //     y or z, whose points fail the distance test by construction).  The scan is one software-pipelined loop over
 //     ~208 consecutive LDS slots, the same trip count for every lane: no rows, no run queue, no per-lane pace;
-//   * hits (d2 <= tau, tau = min(provable radius, density-scaled cap)^2) are a bit mask of the run's slots in
-//     eight registers (v_cmp + v_addc per candidate, no LDS store in the scan loop); the set bits are then written
-//     as run positions (one byte each) to a per-lane ring, read back four at a time, and turned into 64 sort keys:
-//     upper 24 bits of the canonical d2 | position;
+//   * hits (d2 <= tau, tau = min(provable radius, density-scaled cap)^2) are a bit mask of the run's slots: one
+//     v_cmp + v_addc per candidate into the word being filled, a finished word (32 slots) parked in the lane's ring —
+//     one LDS store per 32 candidates, and the loop is the code of one word; the eight words are read back, their set
+//     bits written as run positions (one byte each) to the same ring, read back four at a time, and turned into 64
+//     sort keys: upper 24 bits of the canonical d2 | position;
 //   * one 64-key Batcher network (VGPRs); the first k + 2 entries are looked up again for their exact (d2, id),
 //     put in canonical order where the truncated keys tie, and certified against tau.
 //
