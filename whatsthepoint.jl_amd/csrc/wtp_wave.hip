@@ -40,7 +40,11 @@ template <> struct Bits<double> {
     static constexpr U kInf = 0x7FF0000000000000ull;
 };
 
-template <typename T> struct WaveSmem {
+// SWEEP: the slot of every candidate (the force terms fetch the point again) and the k force terms; topology rows need
+// neither — 10.5 KB per wave instead of 17.6 KB (fp32), i.e. 15 instead of 9 waves per CU: the kernel serves hand-backs one
+// query per wave, so its run time is (queries / resident waves) x the latency of one query
+template <typename T, bool SWEEP> struct WaveSmem;
+template <typename T> struct WaveSmem<T, true> {
     T d2[kCap];
     int32_t id[kCap];
     int32_t slot[kCap];
@@ -51,6 +55,14 @@ template <typename T> struct WaveSmem {
     int32_t oid[kGenericKMax];
     int32_t oslot[kGenericKMax];
     T fx[kGenericKMax], fy[kGenericKMax], fz[kGenericKMax];
+};
+template <typename T> struct WaveSmem<T, false> {
+    T d2[kCap];
+    int32_t id[kCap];
+    T sd2[kSurv];
+    int32_t sid[kSurv];
+    T od2[kGenericKMax];
+    int32_t oid[kGenericKMax];
 };
 
 __device__ inline int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0)); }
@@ -64,8 +76,9 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
     using U = typename Bits<T>::U;
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    WaveSmem<T>* sm = reinterpret_cast<WaveSmem<T>*>(smem_raw) + wave;
-    Acc* sm_acc = reinterpret_cast<Acc*>(smem_raw + sizeof(WaveSmem<T>) * kWaves);
+    using Smem = WaveSmem<T, MODE == 1>;
+    Smem* sm = reinterpret_cast<Smem*>(smem_raw) + wave;
+    Acc* sm_acc = reinterpret_cast<Acc*>(smem_raw + sizeof(Smem) * kWaves);
     const Grid<T> g = *a.grid;
     const int nq = all ? a.n : *list_count;
     const int K = a.k;
@@ -134,7 +147,7 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
                 if (take && pos < kCap) {
                     sm->d2[pos] = d;
                     sm->id[pos] = cid;
-                    sm->slot[pos] = p;
+                    if constexpr (MODE == 1) sm->slot[pos] = p;
                 }
                 m += __popcll(mask);
                 if (m > kCap) overflow = true;
@@ -279,7 +292,7 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
                 if (take && pos < kSurv) {
                     sm->sd2[pos] = sm->d2[i];
                     sm->sid[pos] = sm->id[i];
-                    sm->sslot[pos] = sm->slot[i];
+                    if constexpr (MODE == 1) sm->sslot[pos] = sm->slot[i];
                 }
                 ns += __popcll(mask);
             }
@@ -301,12 +314,12 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
             if (rank < Kq) {
                 sm->od2[rank] = md;
                 sm->oid[rank] = mi;
-                sm->oslot[rank] = sm->sslot[i];
+                if constexpr (MODE == 1) sm->oslot[rank] = sm->sslot[i];
             }
         }
         __builtin_amdgcn_wave_barrier();
 
-        if (MODE == 0) {
+        if constexpr (MODE == 0) {
             for (int j = lane; j < K; j += 64) {
                 a.idx_out[(int64_t)id * K + j] = sm->oid[j];
                 if (a.dist_out) a.dist_out[(int64_t)id * K + j] = wsqrt(sm->od2[j]);
@@ -538,7 +551,7 @@ __global__ __launch_bounds__(kThreads) void wave_radius_kernel(SearchArgs<T> a, 
     }
 }
 
-template <typename T> static size_t wave_smem() { return sizeof(WaveSmem<T>) * kWaves + sizeof(Acc) * kWaves; }
+template <typename T, int MODE> static size_t wave_smem() { return sizeof(WaveSmem<T, MODE == 1>) * kWaves + sizeof(Acc) * kWaves; }
 
 template <typename T>
 int launch_wave_radius_count(wtp_ctx* ctx, SearchArgs<T>& a, T r, int32_t* d_counts, const int32_t* list,
@@ -567,7 +580,7 @@ int launch_wave_radius_fill(wtp_ctx* ctx, SearchArgs<T>& a, T r, const int64_t* 
 }
 
 template <typename T, int MODE> static int launch_wave(wtp_ctx* ctx, SearchArgs<T>& a, bool all, int part_base) {
-    (void)launch_occupancy_of(ctx, (const void*)wave_kernel<T, MODE>, kThreads, wave_smem<T>());
+    (void)launch_occupancy_of(ctx, (const void*)wave_kernel<T, MODE>, kThreads, (wave_smem<T, MODE>()));
     // hand-back lists are a small fraction of the cloud: size the grid by the cloud, not by the chip
     // (an idle block still pays its reduction and its partial: 27 us per step at 47 k points with 2048)
     int64_t want = all ? ((int64_t)a.n + kWaves - 1) / kWaves : (int64_t)a.n / 256;
@@ -575,7 +588,8 @@ template <typename T, int MODE> static int launch_wave(wtp_ctx* ctx, SearchArgs<
     if (!all && want < 64) want = 64;
     int nb = (int)(want > kWavePartials ? kWavePartials : (want < 1 ? 1 : want));
     if (MODE == 1) a.used_wave = nb;
-    hipLaunchKernelGGL((wave_kernel<T, MODE>), dim3(nb), dim3(kThreads), wave_smem<T>(), ctx->stream, a, a.fb_list,
+    const size_t smem_bytes = wave_smem<T, MODE>();
+    hipLaunchKernelGGL((wave_kernel<T, MODE>), dim3(nb), dim3(kThreads), smem_bytes, ctx->stream, a, a.fb_list,
                        a.fb_count, all ? 1 : 0, part_base);
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;
