@@ -338,7 +338,7 @@ def _graded_legs(out, ctx, np, wtp_amd, time, torch):
                 "the law (1-NN in the boundary kd-tree) is evaluated at every movable point before every sweep"}
     # RadiusTopology on the same cloud (fp32 and fp64), r = 2.5 h_wall
     for name, xx in (("f32", xg), ("f64", xg.astype(np.float64))):
-        ctx.radius(xx[:200000], 2.5 * hw)
+        ctx.radius(xx, 2.5 * hw)  # (full size: the call's scratch — parked rows, 320 B per point — is allocated and touched once)
         ctx.timers_reset()
         t0 = time.perf_counter()
         off, _ = ctx.radius(xx, 2.5 * hw)
