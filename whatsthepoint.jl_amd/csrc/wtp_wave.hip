@@ -22,7 +22,7 @@ namespace wtp {
 
 static constexpr int kWaves = 4;             // waves per workgroup
 static constexpr int kThreads = kWaves * 64;
-static constexpr int kCap = 1024;            // candidates buffered per wave
+static constexpr int kCap = 512;             // candidates buffered per wave (1024 until round 3: the list is what limits the waves per CU, and the kernel is latency-bound)
 static constexpr int kKeyRegs = kCap / 64;
 static constexpr int kSurv = 256;            // survivors (d2 <= cut) ranked per wave
 
