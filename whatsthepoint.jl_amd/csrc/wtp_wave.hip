@@ -54,8 +54,9 @@ template <typename T> struct WaveSmem<T, true> {
     T od2[kGenericKMax]; // sorted first k
     int32_t oid[kGenericKMax];
     int32_t oslot[kGenericKMax];
-    T fx[kGenericKMax], fy[kGenericKMax], fz[kGenericKMax];
+    // (the k force terms live in d2[], which is dead once the first k are ranked: 3 x kGenericKMax <= kCap)
 };
+static_assert(3 * kGenericKMax <= kCap, "the force terms reuse the candidate list");
 template <typename T> struct WaveSmem<T, false> {
     T d2[kCap];
     int32_t id[kCap];
@@ -326,15 +327,18 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
             }
         } else {
             const T s = a.spacing_pp ? a.spacing_pp[id] : a.spacing_const;
+            T* const sfx = sm->d2;
+            T* const sfy = sm->d2 + kGenericKMax;
+            T* const sfz = sm->d2 + 2 * kGenericKMax;
             for (int j = lane; j < Kq; j += 64) {
                 T fx = 0, fy = 0, fz = 0;
                 if (sm->oid[j] != id) {
                     const Pt<T> c = a.snap[sm->oslot[j]];
                     add_force<T>(a, g.dim, s, q.x, q.y, q.z, id, c.x, c.y, c.z, sm->oid[j], sm->od2[j], fx, fy, fz);
                 }
-                sm->fx[j] = fx;
-                sm->fy[j] = fy;
-                sm->fz[j] = fz;
+                sfx[j] = fx;
+                sfy[j] = fy;
+                sfz[j] = fz;
             }
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) {
@@ -347,9 +351,9 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
                         nid = sm->oid[j];
                         nd = wsqrt(sm->od2[j]);
                     }
-                    Fx = Fx + sm->fx[j];
-                    Fy = Fy + sm->fy[j];
-                    Fz = Fz + sm->fz[j];
+                    Fx = Fx + sfx[j];
+                    Fy = Fy + sfy[j];
+                    Fz = Fz + sfz[j];
                 }
                 Pt<T> o;
                 const T f = step_point<T>(a, s, q.x, q.y, q.z, Fx, Fy, Fz, o.x, o.y, o.z);
