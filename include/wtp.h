@@ -394,6 +394,8 @@ typedef struct wtp_block_info {
     int32_t host_syncs;         /* host synchronisations this call made (1 in steady state)                       */
     int32_t redone;             /* 1 if the step was undone and repeated with a wider layer                       */
     double ghost_width;         /* current w                                                                      */
+    int32_t overlapped;         /* 1 if the owned points were ranked into the cells while the ghost rows travelled */
+    int32_t reserved;
 } wtp_block_info;
 
 /* Optional transport in place of the context's RCCL communicator (MPI without GPU awareness, tests with several ranks

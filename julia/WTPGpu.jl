@@ -246,6 +246,7 @@ end
 mutable struct BlockInfo
     n_owned::Int64; n_ghost::Int64; n_sent_rows::Int64; n_recv_rows::Int64; n_emigrated::Int64; n_immigrated::Int64
     n_peers::Int32; widened::Int32; host_syncs::Int32; redone::Int32; ghost_width::Float64
+    overlapped::Int32; reserved::Int32
     BlockInfo() = new()
 end
 block_grid(nranks::Int) = (p = Vector{Cint}(undef, 3); ccall((:wtp_block_grid, lib), Cint, (Cint, Ptr{Cint}), nranks, p); Tuple(Int.(p)))

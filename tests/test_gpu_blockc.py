@@ -101,6 +101,27 @@ def test_octants_with_the_product_engine_match_single_domain(wtp):
         assert hists[0][i]["n_move"] == n
 
 
+def test_ranking_the_owned_points_under_the_exchange_changes_nothing(wtp, monkeypatch):
+    """SURVEY 8e "interior work overlaps the exchange": in iterations where nobody migrates the first pass of the rebuild
+    (owned points ranked into the cells) is issued before the ghost rows are in; the rebuild then ranks the appended
+    rows only.  Same cells, same canonical order inside them: bit-identical to the serial chain (WTP_BLOCK_OVERLAP=0)."""
+    from whatsthepoint_jl_amd import blockc
+
+    n, iters = 200_000, 8
+    x = wtp.synth.uniform(n, 3, np.float32)
+    s = float(n) ** (-1.0 / 3.0)
+    boxes = blockc.orthtree_boxes(None, 4, equal_count=False)
+    p1, h1 = _run_blocks(wtp, x, boxes, s, iters, s / 20, w=2.2 * s, margin=0.5 * s)
+    monkeypatch.setenv("WTP_BLOCK_OVERLAP", "0")
+    p0, h0 = _run_blocks(wtp, x, boxes, s, iters, s / 20, w=2.2 * s, margin=0.5 * s)
+    assert np.array_equal(p1, p0)
+    assert [[h["max_force"] for h in hh] for hh in h1] == [[h["max_force"] for h in hh] for hh in h0]
+    assert all(h["overlapped"] == 0 for hh in h0 for h in hh)
+    quiet = [h for hh in h1 for h in hh[2:] if h["n_emigrated"] == 0 and h["n_immigrated"] == 0]
+    assert quiet and sum(h["overlapped"] for h in quiet) >= len(quiet) // 2, [[h["overlapped"] for h in hh] for hh in h1]
+    assert all(h["overlapped"] == 0 for hh in h1 for h in hh if h["n_emigrated"] or h["n_immigrated"])
+
+
 def test_thin_ghost_layer_is_widened_and_the_step_repeated(wtp):
     from whatsthepoint_jl_amd import blockc
 

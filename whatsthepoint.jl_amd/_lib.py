@@ -54,7 +54,8 @@ class BlockDesc(C.Structure):
 class BlockInfo(C.Structure):
     _fields_ = [("n_owned", C.c_int64), ("n_ghost", C.c_int64), ("n_sent_rows", C.c_int64), ("n_recv_rows", C.c_int64),
                 ("n_emigrated", C.c_int64), ("n_immigrated", C.c_int64), ("n_peers", C.c_int32), ("widened", C.c_int32),
-                ("host_syncs", C.c_int32), ("redone", C.c_int32), ("ghost_width", C.c_double)]
+                ("host_syncs", C.c_int32), ("redone", C.c_int32), ("ghost_width", C.c_double), ("overlapped", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)

@@ -688,6 +688,9 @@ WTP_API int wtp_destroy(wtp_ctx* ctx) {
         if (b->p) hipFree(b->p);
     if (ctx->host_pinned) hipHostFree(ctx->host_pinned);
     for (auto e : ctx->ev_pool) hipEventDestroy(e);
+    if (ctx->ev_comm_a) hipEventDestroy(ctx->ev_comm_a);
+    if (ctx->ev_comm_b) hipEventDestroy(ctx->ev_comm_b);
+    if (ctx->comm_stream) hipStreamDestroy(ctx->comm_stream);
     hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return WTP_OK;
@@ -1370,6 +1373,7 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
                                min_cell, r.cell_scale);
             ctx->reuse_grid = false;
         }
+        r.last_rho_cs = rho_cs;
         span_end(ctx, sp);
         ctx->hash_view.active = false;
         if (rc) return rc;
@@ -1481,6 +1485,28 @@ static int relax_step_any(wtp_ctx* ctx, int rebuild, wtp_step_stats* d_slot) {
                                        : relax_step_t<double>(ctx, rebuild, d_slot);
 }
 int wtp::relax_step_enqueue(wtp_ctx* ctx, int rebuild, wtp_step_stats* d_slot) { return relax_step_any(ctx, rebuild, d_slot); }
+
+// The block driver knows, before the ghost rows of an iteration have arrived, how many there will be.  When the rebuild that
+// follows is going to keep its grid (the same rule as in relax_step_t), the snapshot's own entries are ranked into the
+// cells right away, on the context's stream, while the rows travel on another; build_hash then ranks the appended head
+// only.  A wrong guess costs one wasted pass, never a wrong result (build_hash checks what it finds).
+int wtp::relax_prerank(wtp_ctx* ctx, int64_t n_fixed_new) {
+    RelaxState& r = ctx->relax;
+    ctx->prerank.valid = false;
+    if (!r.active || !r.grid_tuned || !r.have_tree || r.pending.active || r.moved_by_hand || ctx->box_active) return WTP_OK;
+    if (r.grid_age >= ctx->grid_reuse_max || !r.shard_grid_reuse || r.grid_fixed <= 0) return WTP_OK;
+    if (std::llabs((long long)(n_fixed_new - r.grid_fixed)) * 10 > (long long)r.grid_fixed + 640) return WTP_OK;
+    const int64_t n_new = r.n - r.n_fixed + n_fixed_new;
+    if (r.cs2_bx > 0 && std::llabs((long long)(n_fixed_new - r.tuned_fixed)) * 20 > (long long)n_new) return WTP_OK;
+    const size_t ptsz = r.dtype == WTP_F32 ? sizeof(float4) : sizeof(double4);
+    if (ctx->pts[r.bufP].cap < ptsz * (size_t)(r.n + n_fixed_new)) return WTP_OK; // (the head would be rewritten, not appended)
+    const int k = (int64_t)r.k_req < n_new ? r.k_req : (int)n_new;
+    if (r.dtype == WTP_F32)
+        return prerank_old_snapshot<float>(ctx, (const Pt<float>*)ctx->pts[r.bufP].p, r.n, (int32_t)r.n_fixed, n_new, r.n + n_fixed_new,
+                                           k, r.last_rho_cs, r.cell_scale);
+    return prerank_old_snapshot<double>(ctx, (const Pt<double>*)ctx->pts[r.bufP].p, r.n, (int32_t)r.n_fixed, n_new, r.n + n_fixed_new,
+                                        k, r.last_rho_cs, r.cell_scale);
+}
 
 // The movable set of a session is replaced as a whole (block decomposition: points migrated in and out).  The caller
 // writes the new points {x, y, z, bits(index)} into the buffer relax_swap_begin hands out and commits: the session then

@@ -66,6 +66,7 @@ struct BlockState {
     std::vector<int64_t> send_cnt, mig_cnt, recv_cnt, rmig_cnt;
     // transport
     bool host_transport = false;
+    bool overlap = true; // the owned points are ranked into the cells while the ghost rows travel (WTP_BLOCK_OVERLAP=0: after them)
     wtp_transport tr{};
     std::vector<unsigned char> hbuf_a, hbuf_b;
     // last info
@@ -626,6 +627,7 @@ WTP_API int wtp_block_open(wtp_ctx* ctx, const wtp_block_desc* desc, const void*
     if (!ctx->block) ctx->block = new BlockState();
     BlockState* b = bs_of(ctx);
     if (b->active) return fail(ctx, WTP_ERR_STATE, "wtp_block_open: a block session is open already");
+    if (const char* e = getenv("WTP_BLOCK_OVERLAP")) b->overlap = atoi(e) != 0; // (A/B switch)
     if (!b->host_transport && desc->nranks > 1 && (!ctx->comm || ctx->comm_size != desc->nranks || ctx->comm_rank != desc->rank))
         return fail(ctx, WTP_ERR_STATE, "wtp_block_open: wtp_comm_init (same rank / nranks) or wtp_block_set_transport first");
     for (int r = 0; r < desc->nranks; ++r)
@@ -663,6 +665,14 @@ WTP_API int wtp_block_open(wtp_ctx* ctx, const wtp_block_desc* desc, const void*
     return WTP_OK;
 }
 
+// second stream and the two events that tie it to the first (created on first use)
+static int blk_streams(wtp_ctx* ctx) {
+    if (!ctx->comm_stream) WTP_HIP(ctx, hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    if (!ctx->ev_comm_a) WTP_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_comm_a, hipEventDisableTiming));
+    if (!ctx->ev_comm_b) WTP_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_comm_b, hipEventDisableTiming));
+    return WTP_OK;
+}
+
 // the exchange the plan describes: ghost rows into the pool, migrants into recv_mig; then the owned set and the ghosts
 static int blk_exchange_and_apply(wtp_ctx* ctx, BlockState* b) {
     RelaxState& r = ctx->relax;
@@ -678,6 +688,8 @@ static int blk_exchange_and_apply(wtp_ctx* ctx, BlockState* b) {
     const int64_t n_pool = n_recv + n_mig; // peers' rows + my own emigrants
     if ((rc = ensure(ctx, b->pool, 16 * (size_t)(n_pool + 16)))) return rc;
     if ((rc = ensure(ctx, b->recv_mig, 32 * (size_t)(n_rmig + 16)))) return rc;
+    // nobody crosses in this iteration (the usual case): the owned set stays, so its part of the rebuild can start early
+    const bool early = b->overlap && np > 0 && n_mig == 0 && n_rmig == 0;
     // messages: per peer (ascending rank) ghosts, then migrants
     std::vector<int> peers;
     std::vector<const void*> sp;
@@ -710,7 +722,16 @@ static int blk_exchange_and_apply(wtp_ctx* ctx, BlockState* b) {
             unsigned char* hb = b->hbuf_b.data();
             if (n_send) WTP_HIP(ctx, hipMemcpyAsync(ha, b->send.p, 16 * (size_t)n_send, hipMemcpyDeviceToHost, ctx->stream));
             if (n_mig) WTP_HIP(ctx, hipMemcpyAsync(ha + 16 * (size_t)n_send, b->send_mig.p, 32 * (size_t)n_mig, hipMemcpyDeviceToHost, ctx->stream));
-            if ((rc = blk_sync(ctx, b))) return rc;
+            if (early) {
+                // the host waits for the rows only; the stream goes on ranking the owned points under the callback
+                if ((rc = blk_streams(ctx))) return rc;
+                WTP_HIP(ctx, hipEventRecord(ctx->ev_comm_a, ctx->stream));
+                if ((rc = relax_prerank(ctx, n_pool))) return rc;
+                ctx->ev_last_end = -1;
+                WTP_HIP(ctx, hipEventSynchronize(ctx->ev_comm_a));
+                ctx->n_syncs += 1;
+            } else if ((rc = blk_sync(ctx, b)))
+                return rc;
             std::vector<const void*> hs(sp.size());
             std::vector<void*> hr(rp.size());
             std::vector<int64_t> sb(sp.size()), rb(rp.size());
@@ -727,6 +748,20 @@ static int blk_exchange_and_apply(wtp_ctx* ctx, BlockState* b) {
             if (n_recv) WTP_HIP(ctx, hipMemcpyAsync(b->pool.p, hb, 16 * (size_t)n_recv, hipMemcpyHostToDevice, ctx->stream));
             if (n_rmig) WTP_HIP(ctx, hipMemcpyAsync(b->recv_mig.p, hb + 16 * (size_t)n_recv, 32 * (size_t)n_rmig, hipMemcpyHostToDevice, ctx->stream));
             if ((rc = blk_sync(ctx, b))) return rc; // (the host buffers are reused)
+        } else if (early) {
+            // Exchange and compute overlap: the grouped round runs on the context's second stream, every peer on
+            // its own link; the first stream ranks the owned points into the cells meanwhile (the first pass of the rebuild,
+            // which does not need the ghosts) and waits for the rows only before it appends them.
+            if ((rc = blk_streams(ctx))) return rc;
+            WTP_HIP(ctx, hipEventRecord(ctx->ev_comm_a, ctx->stream)); // (send rows and the pool's last readers are in stream order before it)
+            WTP_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->ev_comm_a, 0));
+            if ((rc = comm_exchange_peers_on(ctx, ctx->comm_stream, (int)peers.size(), peers.data(), sp.data(), sn.data(), rp.data(),
+                                             rn.data())))
+                return rc;
+            WTP_HIP(ctx, hipEventRecord(ctx->ev_comm_b, ctx->comm_stream));
+            rc = relax_prerank(ctx, n_pool);
+            WTP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_comm_b, 0)); // (also when the ranking failed: the streams join again)
+            if (rc) return rc;
         } else {
             if ((rc = wtp_comm_exchange_peers(ctx, (int)peers.size(), peers.data(), sp.data(), sn.data(), rp.data(), rn.data()))) return rc;
         }
@@ -775,7 +810,7 @@ WTP_API int wtp_block_step(wtp_ctx* ctx, wtp_step_stats* stats, wtp_block_info* 
     if (!b || !b->active) return fail(ctx, WTP_ERR_STATE, "wtp_block_step before wtp_block_open");
     WTP_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
-    const int64_t syncs0 = ctx->n_syncs;
+    const int64_t syncs0 = ctx->n_syncs, pre0 = ctx->preranked_builds;
     b->info.redone = 0;
     if ((rc = ensure(ctx, ctx->stats, sizeof(wtp_step_stats)))) return rc;
     wtp_step_stats g{};
@@ -804,6 +839,8 @@ WTP_API int wtp_block_step(wtp_ctx* ctx, wtp_step_stats* stats, wtp_block_info* 
         g.argmin_j = -1;
     }
     b->info.host_syncs = (int32_t)(ctx->n_syncs - syncs0);
+    b->info.overlapped = (int32_t)(ctx->preranked_builds - pre0);
+    b->info.reserved = 0;
     b->info.n_owned = b->n_owned;
     b->info.n_ghost = b->n_ghost;
     b->info.n_peers = b->geom.np;

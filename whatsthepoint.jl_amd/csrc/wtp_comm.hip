@@ -221,6 +221,13 @@ WTP_API int wtp_comm_allreduce_stats(wtp_ctx* ctx, wtp_step_stats* st) {
 WTP_API int wtp_comm_exchange_peers(wtp_ctx* ctx, int n_msgs, const int* peers, const void* const* d_send,
                                     const int64_t* n_send, void* const* d_recv, const int64_t* n_recv) {
     if (!ctx) return WTP_ERR_ARG;
+    return wtp::comm_exchange_peers_on(ctx, ctx->stream, n_msgs, peers, d_send, n_send, d_recv, n_recv);
+}
+
+// (the same round on a stream of the caller's choosing: the block driver posts it on the context's second stream and lets
+// the first one rank the owned points meanwhile)
+int wtp::comm_exchange_peers_on(wtp_ctx* ctx, hipStream_t stream, int n_msgs, const int* peers, const void* const* d_send,
+                                const int64_t* n_send, void* const* d_recv, const int64_t* n_recv) {
     if (!ctx->comm) return fail(ctx, WTP_ERR_STATE, "wtp_comm_exchange_peers before wtp_comm_init");
     if (n_msgs < 0 || (n_msgs > 0 && (!peers || !d_send || !n_send || !d_recv || !n_recv)))
         return fail(ctx, WTP_ERR_ARG, "wtp_comm_exchange_peers: NULL argument");
@@ -237,8 +244,8 @@ WTP_API int wtp_comm_exchange_peers(wtp_ctx* ctx, int n_msgs, const int* peers, 
     if (!any) return WTP_OK;
     WTP_NCCL(ctx, g_rccl.GroupStart());
     for (int j = 0; j < n_msgs; ++j) {
-        if (n_send[j] > 0) WTP_NCCL(ctx, g_rccl.Send(d_send[j], (size_t)n_send[j] * 16, ncclUint8, peers[j], comm, ctx->stream));
-        if (n_recv[j] > 0) WTP_NCCL(ctx, g_rccl.Recv(d_recv[j], (size_t)n_recv[j] * 16, ncclUint8, peers[j], comm, ctx->stream));
+        if (n_send[j] > 0) WTP_NCCL(ctx, g_rccl.Send(d_send[j], (size_t)n_send[j] * 16, ncclUint8, peers[j], comm, stream));
+        if (n_recv[j] > 0) WTP_NCCL(ctx, g_rccl.Recv(d_recv[j], (size_t)n_recv[j] * 16, ncclUint8, peers[j], comm, stream));
     }
     WTP_NCCL(ctx, g_rccl.GroupEnd());
     return WTP_OK;

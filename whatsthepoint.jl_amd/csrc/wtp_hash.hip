@@ -787,22 +787,15 @@ int launch_occupancy(wtp_ctx* ctx, unsigned long long* d_out3) {
     return WTP_OK;
 }
 
-template <typename T>
-int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, int k, double radius, double rho_direct,
-               double min_cell, double cell_scale) {
-    if (!(cell_scale > 0)) cell_scale = 1.0;
+// The per-build scratch (cell counts and starts, one rank per input entry, the dirty map, the scan's block sums), sized for
+// a structure of n points read from n_in input entries; *fresh = the counts or the map moved (their contents are gone).
+static int hash_scratch(wtp_ctx* ctx, int64_t n, int64_t n_in, int k, double radius, double rho_direct, double cell_scale,
+                        int* cap_out, bool* fresh) {
     // k-equivalent of the occupancy the caller fixed (rho = 8 <-> k = 21)
     const int k_cap = rho_direct > 0 ? (int)(rho_direct * 21.0 / ctx->rho) : (radius > 0 ? 6 : k);
     const int cap = cell_capacity(ctx, n, k_cap > 0 ? k_cap : 1, cell_scale);
     int rc;
     if ((rc = ensure(ctx, ctx->grid, sizeof(Grid<double>)))) return rc;
-    // n = points of the structure; the input array may be longer (ctx->hash_view: stale fixed points
-    // still in place, new ones appended)
-    const HashView hv = ctx->hash_view;
-    const int64_t n_in = hv.active ? hv.n_in : n;
-    const int64_t v_old = hv.active ? hv.n_old : 0;
-    const int32_t v_fixed_old = hv.active ? hv.fixed_old : 0, v_shift = hv.active ? hv.id_shift : 0;
-    const int nbb = grid_for(n_in, kThreads, 1024);
     if ((rc = ensure(ctx, ctx->bbox_part, sizeof(double) * 6 * 1024))) return rc;
     const void* cnt_before = ctx->cell_cnt.p;
     const void* dirty_before = ctx->rank_of.p;
@@ -812,6 +805,62 @@ int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, in
     if ((rc = ensure(ctx, ctx->rank_of, (size_t)cap + 64))) return rc; // one byte per cell: filled by more than one run of the input
     const int nscan = (cap + kScanTile - 1) / kScanTile;
     if ((rc = ensure(ctx, ctx->scan_tmp, sizeof(int32_t) * (size_t)(nscan + 1)))) return rc;
+    *cap_out = cap;
+    *fresh = cnt_before != ctx->cell_cnt.p || dirty_before != ctx->rank_of.p;
+    return WTP_OK;
+}
+
+// First half of the next build_hash, issued early: the entries [0, n_old) of `in` (the snapshot as it stands, its fixed
+// head of fixed_old points stale) are ranked into the cells of the grid in place, which the build is going to keep
+// (ctx->reuse_grid).  The build that follows appends n_in - n_old new entries and ranks only those (block driver: the
+// owned points are ranked while the ghost rows travel).  Nothing depends on the guess being right: build_hash
+// checks ctx->prerank against what it is asked to build and otherwise starts over.
+template <typename T>
+int prerank_old_snapshot(wtp_ctx* ctx, const Pt<T>* in, int64_t n_old, int32_t fixed_old, int64_t n_next, int64_t n_in_next,
+                         int k, double rho_direct, double cell_scale) {
+    if (!(cell_scale > 0)) cell_scale = 1.0;
+    int cap = 0, rc;
+    bool fresh = false;
+    ctx->prerank.valid = false;
+    if ((rc = hash_scratch(ctx, n_next, n_in_next, k, 0.0, rho_direct, cell_scale, &cap, &fresh))) return rc;
+    int32_t* cnt = (int32_t*)ctx->cell_cnt.p;
+    uint8_t* dirty = (uint8_t*)ctx->rank_of.p;
+    if (!ctx->hash_scratch_clean || fresh) {
+        WTP_HIP(ctx, hipMemsetAsync(cnt, 0, ctx->cell_cnt.cap, ctx->stream));
+        WTP_HIP(ctx, hipMemsetAsync(dirty, 0, ctx->rank_of.cap, ctx->stream));
+    }
+    ctx->hash_scratch_clean = false; // (the counts hold the first half from here on)
+    const int nb = grid_for(n_old, kThreads, 16384);
+    hipLaunchKernelGGL(cell_rank_kernel<T>, dim3(nb), dim3(kThreads), 0, ctx->stream, in, n_old, (const Grid<T>*)ctx->grid.p, cnt,
+                       (int32_t*)ctx->cell_of.p, ctx->topology_build ? (uint8_t*)nullptr : dirty, n_old, fixed_old, ctx->stop_dev);
+    WTP_HIP(ctx, hipGetLastError());
+    ctx->prerank.valid = true;
+    ctx->prerank.in = in;
+    ctx->prerank.n_old = n_old;
+    ctx->prerank.fixed_old = fixed_old;
+    ctx->prerank.cnt = cnt;
+    ctx->prerank.cr = ctx->cell_of.p;
+    ctx->prerank.dirty = dirty;
+    return WTP_OK;
+}
+template int prerank_old_snapshot<float>(wtp_ctx*, const Pt<float>*, int64_t, int32_t, int64_t, int64_t, int, double, double);
+template int prerank_old_snapshot<double>(wtp_ctx*, const Pt<double>*, int64_t, int32_t, int64_t, int64_t, int, double, double);
+
+template <typename T>
+int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, int k, double radius, double rho_direct,
+               double min_cell, double cell_scale) {
+    if (!(cell_scale > 0)) cell_scale = 1.0;
+    // n = points of the structure; the input array may be longer (ctx->hash_view: stale fixed points
+    // still in place, new ones appended)
+    const HashView hv = ctx->hash_view;
+    const int64_t n_in = hv.active ? hv.n_in : n;
+    const int64_t v_old = hv.active ? hv.n_old : 0;
+    const int32_t v_fixed_old = hv.active ? hv.fixed_old : 0, v_shift = hv.active ? hv.id_shift : 0;
+    const int nbb = grid_for(n_in, kThreads, 1024);
+    int cap = 0, rc;
+    bool fresh = false;
+    if ((rc = hash_scratch(ctx, n, n_in, k, radius, rho_direct, cell_scale, &cap, &fresh))) return rc;
+    const int nscan = (cap + kScanTile - 1) / kScanTile;
 
     Grid<T>* g = (Grid<T>*)ctx->grid.p;
     T* part = (T*)ctx->bbox_part.p;
@@ -830,16 +879,24 @@ int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, in
     // Counts and dirty map are consumed (zeroed) by the scan and by the canonical-order pass of every build, so
     // a build normally finds them all-zero: the two fills (4 + 1 bytes per cell) run only after a reallocation or
     // after a build that did not complete.
-    if (!ctx->hash_scratch_clean || cnt_before != ctx->cell_cnt.p || dirty_before != ctx->rank_of.p) {
-        WTP_HIP(ctx, hipMemsetAsync(cnt, 0, ctx->cell_cnt.cap, st));
-        WTP_HIP(ctx, hipMemsetAsync(dirty, 0, ctx->rank_of.cap, st));
-    }
-    ctx->hash_scratch_clean = false;
     // ctx->reuse_grid (one-shot, set by the relax session): keep the Grid of the previous build — origin, cell edge,
     // cell counts — and skip the bounding-box pass.  A point that has left the old box since is clamped into an
     // edge cell, which the kernels treat as unbounded outward, so the search stays exact.
     const bool reuse = ctx->reuse_grid;
     ctx->reuse_grid = false;
+    // the old snapshot's entries may have been ranked already (prerank_old_snapshot): same array, same view, same
+    // scratch, same grid — then only the appended entries are left
+    const Prerank pre = ctx->prerank;
+    ctx->prerank.valid = false;
+    const bool half_done = pre.valid && reuse && hv.active && !fresh && pre.in == (const void*)in && pre.n_old == v_old &&
+                           pre.fixed_old == v_fixed_old && pre.cnt == (const void*)cnt && pre.cr == (const void*)cr &&
+                           pre.dirty == (const void*)dirty;
+    if (!half_done && (!ctx->hash_scratch_clean || fresh)) {
+        WTP_HIP(ctx, hipMemsetAsync(cnt, 0, ctx->cell_cnt.cap, st));
+        WTP_HIP(ctx, hipMemsetAsync(dirty, 0, ctx->rank_of.cap, st));
+    }
+    ctx->hash_scratch_clean = false;
+    ctx->preranked_builds += half_done ? 1 : 0;
     if (!reuse) {
         hipLaunchKernelGGL(bbox_kernel<T>, dim3(nbb), dim3(kThreads), 0, st, in, n_in, part, v_old, v_fixed_old);
         hipLaunchKernelGGL(grid_setup_kernel<T>, dim3(1), dim3(64), 0, st, part, nbb, g, n, dim, rho_k, radius, min_cell,
@@ -847,8 +904,15 @@ int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, in
     }
     ctx->ncells_dev = &g->ncells;
     const int nb = grid_for(n_in, kThreads, 16384);
-    hipLaunchKernelGGL(cell_rank_kernel<T>, dim3(nb), dim3(kThreads), 0, st, in, n_in, g, cnt, cr,
-                       ctx->topology_build ? (uint8_t*)nullptr : dirty, v_old, v_fixed_old, ctx->stop_dev);
+    if (half_done) {
+        if (n_in > v_old) // (the appended entries: nothing stale among them)
+            hipLaunchKernelGGL(cell_rank_kernel<T>, dim3(grid_for(n_in - v_old, kThreads, 16384)), dim3(kThreads), 0, st, in + v_old,
+                               n_in - v_old, g, cnt, cr + v_old, ctx->topology_build ? (uint8_t*)nullptr : dirty, (int64_t)0, 0,
+                               ctx->stop_dev);
+    } else {
+        hipLaunchKernelGGL(cell_rank_kernel<T>, dim3(nb), dim3(kThreads), 0, st, in, n_in, g, cnt, cr,
+                           ctx->topology_build ? (uint8_t*)nullptr : dirty, v_old, v_fixed_old, ctx->stop_dev);
+    }
     hipLaunchKernelGGL(scan_reduce_kernel<T>, dim3(nscan), dim3(kThreads), 0, st, cnt, g, bs);
     hipLaunchKernelGGL(scan_apply_kernel<T>, dim3(nscan), dim3(kThreads), 0, st, cnt, bs, g, start, ctx->stop_dev);
     hipLaunchKernelGGL(scatter_kernel<T>, dim3(nb), dim3(kThreads), 0, st, in, n_in, cr, g, start, out, v_old, v_fixed_old,

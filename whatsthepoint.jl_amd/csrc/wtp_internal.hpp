@@ -169,6 +169,17 @@ struct HashView {
     int32_t id_shift = 0;
 };
 
+// Part of a hash build issued ahead of time (block driver: while the ghost rows of the iteration travel): the old
+// snapshot's entries [0, n_old) of `in` are already ranked into the cell counts.  One-shot; build_hash takes it over only
+// when every pointer and number still matches, otherwise it zeroes the counts and ranks everything itself.
+struct Prerank {
+    bool valid = false;
+    const void* in = nullptr;
+    int64_t n_old = 0;
+    int32_t fixed_old = 0;
+    const void *cnt = nullptr, *cr = nullptr, *dirty = nullptr;
+};
+
 struct RelaxState {
     bool active = false;
     int64_t n = 0, n_fixed = 0;
@@ -204,6 +215,7 @@ struct RelaxState {
     int swap_target = -1;    // relax_swap_begin .. relax_swap_commit (wtp_block.hip: migration)
     bool shard_grid_reuse = false; // block sessions: the grid is kept across a swapped ghost head (points outside it pile into edge cells, which every search treats as unbounded outward)
     int64_t grid_fixed = -1;       // fixed points the current grid's bounding box was computed with
+    double last_rho_cs = 0.0;      // occupancy argument of the session's last hash build (relax_prerank sizes its scratch alike)
     bool wall_active = false; // octree method: _constrain_octree runs after every sweep (wtp_relax_set_wall)
     double wall_offset = 0;   // inward nudge of a projected boundary point (src/repel.jl:143)
     int64_t wall_nm = 0;      // movable points the wall arrays are sized for
@@ -269,6 +281,10 @@ struct wtp_ctx {
     wtp::DevBuf rad_tmp, rad_done; // RadiusTopology: rows parked by the count phase (32 ids per query), one byte per query
     wtp::DevBuf rad_arena, rad_arena_off; // ... and the wave kernel's rows (any length), their starts; the bump counter sits behind the starts
     wtp::DevBuf brick_dead;    // wtp_cs2.hip, variable spacing: one byte per brick (cs2_dead_kernel)
+    wtp::Prerank prerank;             // wtp_hash.hip: prerank_old_snapshot
+    int64_t preranked_builds = 0;     // hash builds that took a first half over
+    hipStream_t comm_stream = nullptr; // block driver: the grouped exchange runs here while the owned points are ranked
+    hipEvent_t ev_comm_a = nullptr, ev_comm_b = nullptr;
     bool hash_scratch_clean = false;  // cell counts and dirty map are all-zero (every completed build leaves them so)
     bool counters_clean = false;      // the 64-byte counter block is all-zero (the step's final reduction leaves it so)
     wtp::DevBuf stop_state;           // wtp_relax_run_until: {stopped, reason, n_done, last_impr, best_cv} on the device
@@ -352,6 +368,9 @@ void spans_collect(wtp_ctx* ctx);
 template <typename T>
 int build_hash(wtp_ctx* ctx, const Pt<T>* in, Pt<T>* out, int64_t n, int dim, int k, double radius,
                double rho_direct = 0.0, double min_cell = 0.0, double cell_scale = 1.0);
+template <typename T>
+int prerank_old_snapshot(wtp_ctx* ctx, const Pt<T>* in, int64_t n_old, int32_t fixed_old, int64_t n_next, int64_t n_in_next,
+                         int k, double rho_direct, double cell_scale);
 // occupancy of the grid the last build_hash made: d_out3 = [sum cnt^2, sum cnt, max cnt]
 int launch_occupancy(wtp_ctx* ctx, unsigned long long* d_out3);
 template <typename T> int launch_sum(wtp_ctx* ctx, const T* d_v, int64_t n, double* d_out);
@@ -468,6 +487,9 @@ int relax_step_enqueue(wtp_ctx* ctx, int rebuild, wtp_step_stats* d_slot); // on
 int relax_swap_begin(wtp_ctx* ctx, int64_t n_move_new, void** d_buf_out);  // a free point buffer for a replaced movable set ...
 int relax_swap_commit(wtp_ctx* ctx, int64_t n_move_new);                   // ... which becomes the session's P (no fixed head, tuning kept)
 int relax_set_fixed_dev_impl(wtp_ctx* ctx, const void* d_fixed4, int64_t n_fixed_new, bool keep_alive);
+int comm_exchange_peers_on(wtp_ctx* ctx, hipStream_t stream, int n_msgs, const int* peers, const void* const* d_send,
+                           const int64_t* n_send, void* const* d_recv, const int64_t* n_recv); // wtp_comm.hip
+int relax_prerank(wtp_ctx* ctx, int64_t n_fixed_new); // first half of the next rebuild's hash, ahead of wtp_relax_set_fixed_dev (see wtp_api.hip)
 void block_destroy(wtp_ctx* ctx);                                          // frees ctx->block (wtp_destroy)
 template <typename T>
 int launch_refix(wtp_ctx* ctx, const Pt<T>* in, int64_t n_old, int64_t n_fixed_old, int64_t n_fixed_new,
