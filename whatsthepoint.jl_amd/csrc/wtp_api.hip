@@ -680,7 +680,7 @@ WTP_API int wtp_destroy(wtp_ctx* ctx) {
                       &ctx->cell_cnt, &ctx->cell_start, &ctx->scan_tmp, &ctx->grid, &ctx->bbox_part,
                       &ctx->idx_out, &ctx->dist_out, &ctx->counts_out, &ctx->forces, &ctx->nn_dist,
                       &ctx->nn_id, &ctx->spacing_pp, &ctx->partials, &ctx->stats, &ctx->fb_list,
-                      &ctx->fb_count, &ctx->fb2_list, &ctx->fb2_count, &ctx->nn_list, &ctx->brick_dead, &ctx->rad_tmp, &ctx->rad_done, &ctx->rad_arena, &ctx->rad_arena_off, &ctx->scratch, &ctx->diag,
+                      &ctx->fb_count, &ctx->fb2_list, &ctx->fb2_count, &ctx->nn_list, &ctx->brick_dead, &ctx->rad_tmp, &ctx->rad_done, &ctx->rad_arena, &ctx->rad_arena_off, &ctx->rad_pos, &ctx->rad_bricks, &ctx->scratch, &ctx->diag,
                       &ctx->ins_in, &ctx->ins_elems, &ctx->ins_partial, &ctx->ins_out, &ctx->mesh_nodes, &ctx->mesh_pn, &ctx->mesh_io,
                       &ctx->wall_flags, &ctx->wall_tri, &ctx->wall_hint, &ctx->mesh_cls, &ctx->kd_nodes, &ctx->sp_hint, &ctx->occ, &ctx->box_dev,
                       &ctx->cand_idx, &ctx->cand_dist, &ctx->f32_pts, &ctx->comm_scratch, &ctx->sp_cert};
@@ -878,14 +878,26 @@ template <typename T> static int radius_count_t(wtp_ctx* ctx, int64_t n, int dim
             if ((rc = ensure(ctx, ctx->rad_arena_off, sizeof(int64_t) * (size_t)(n + 2)))) return rc;
             a.rad_arena = (int32_t*)ctx->rad_arena.p;
             a.rad_arena_off = (int64_t*)ctx->rad_arena_off.p;
-            a.rad_arena_pos = nullptr;
+            if ((rc = ensure(ctx, ctx->rad_pos, 64))) return rc;
+            WTP_HIP(ctx, hipMemsetAsync(ctx->rad_pos.p, 0, 16, ctx->stream));
+            if ((rc = ensure(ctx, ctx->rad_bricks, sizeof(int32_t) * (size_t)(n + 64)))) return rc;
+            a.rad_bricks = (int32_t*)ctx->rad_bricks.p;
+            a.rad_arena_pos = (unsigned long long*)ctx->rad_pos.p; // the dense kernel takes pieces of the arena (wtp_radb.hip)
             a.rad_arena_cap = arena_cap;
         }
         ctx->rad_rows_cached = true;
     }
     sp = span_begin(ctx, 1);
     rc = launch_radius_count<T>(ctx, a, (T)r, d_counts);
+    ctx->rad_dense_used = a.rad_dense > 0;
     span_end(ctx, sp);
+    if (!rc && a.rad_dense > 0 && getenv("WTP_DEBUG")) {
+        int32_t h[4] = {0, 0, 0, 0};
+        WTP_HIP(ctx, hipMemcpyAsync(h, ctx->rad_pos.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+        WTP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        fprintf(stderr, "[wtp] radius, dense kernel: %d bricks, %d of %lld queries, %lld ids parked\n", h[2], h[3], (long long)n,
+                (long long)(((unsigned long long)(uint32_t)h[1] << 32) | (uint32_t)h[0]));
+    }
     return rc;
 }
 
@@ -908,6 +920,7 @@ template <typename T> static int radius_fill_t(wtp_ctx* ctx, const int64_t* d_of
             a.rad_arena_off = (int64_t*)ctx->rad_arena_off.p;
             a.rad_arena_cap = 48 * ctx->rad_n;
         }
+        a.rad_dense = ctx->rad_dense_used ? 1 : 0; // (the hand-back list of the count phase is what is left to search)
     }
     int sp = span_begin(ctx, 1);
     int rc = launch_radius_fill<T>(ctx, a, (T)ctx->rad_r, d_off, d_idx);

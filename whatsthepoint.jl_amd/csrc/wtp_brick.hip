@@ -346,7 +346,9 @@ __global__ __launch_bounds__(kBrickThreads, CS ? 4 : 2) void brick_kernel(Search
         // RadiusTopology: a brick whose cells hold more than ~7.4 points has rows beyond this kernel's 32 entries (a row is
         // ~4.06 cells' worth of points); it is handed to the wave kernel up front, like a brick that does not fit LDS,
         // instead of being staged and scanned first (the dense part of a graded cloud)
-        const bool overflow = halo_total > hcap || (MODE == 2 && halo_total > 1600);
+        const bool overflow = halo_total > hcap || (MODE == 2 && halo_total > kRadDenseMin);
+        // (count phase with the dense kernel behind it, wtp_radb.hip: such a brick is that kernel's, unless it outgrows its LDS too)
+        if (MODE == 2 && a.rad_dense > 0 && halo_total > kRadDenseMin && halo_total <= a.rad_dense) continue;
 
         // ---- 2. own-row prefix (queries = points of the BX*BY*BZ own cells) ------------------
         if (tid == 0) {

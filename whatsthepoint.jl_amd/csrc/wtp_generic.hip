@@ -275,14 +275,23 @@ int launch_radius_count(wtp_ctx* ctx, SearchArgs<T>& a, T r, int32_t* d_counts) 
         WTP_HIP(ctx, hipGetLastError());
         return WTP_OK;
     }
-    if (brick_radius_usable<T>(ctx, a)) { // fp32: LDS-staged brick kernel first, the wave kernel takes what it hands back
+    // the brick-staged wave-per-query kernel (wtp_radb.hip) needs somewhere to park its rows and a list to hand back to
+    const bool dense = !ctx->force_generic && a.rad_done && a.rad_arena && a.rad_arena_pos && a.rad_bricks && a.fb_list && a.fb_count &&
+                       !(getenv("WTP_RADIUS_DENSE") && atoi(getenv("WTP_RADIUS_DENSE")) == 0); // (A/B switch)
+    a.rad_dense = dense ? radius_dense_hcap<T>() : 0;
+    if (brick_radius_usable<T>(ctx, a) || dense) {
+        // fp32: LDS-staged brick kernel first (lane per query, rows up to 32 entries); then the dense bricks (fp64: all bricks),
+        // wave per query from LDS; the wave kernel takes what they hand back
         WTP_HIP(ctx, hipMemsetAsync(a.fb_count, 0, sizeof(int32_t), ctx->stream));
-        a.radius2 = r * r;
-        a.rad_counts = d_counts;
-        a.rad_offsets = nullptr;
-        a.rad_fill = 0;
-        int rc = brick_radius<T>(ctx, a);
-        if (rc) return rc;
+        int rc;
+        if (brick_radius_usable<T>(ctx, a)) {
+            a.radius2 = r * r;
+            a.rad_counts = d_counts;
+            a.rad_offsets = nullptr;
+            a.rad_fill = 0;
+            if ((rc = brick_radius<T>(ctx, a))) return rc;
+        }
+        if (dense && (rc = launch_radius_dense<T>(ctx, a, r, d_counts))) return rc;
         return launch_wave_radius_count<T>(ctx, a, r, d_counts, a.fb_list, a.fb_count);
     }
     return launch_wave_radius_count<T>(ctx, a, r, d_counts, nullptr, nullptr);
@@ -308,7 +317,7 @@ int launch_radius_fill(wtp_ctx* ctx, SearchArgs<T>& a, T r, const int64_t* d_off
         hipLaunchKernelGGL(radius_copy_rows_kernel, dim3(blocks_for((int64_t)a.n * 16, 16384)), dim3(kThreads), 0, ctx->stream,
                            (int64_t)a.n, (const int32_t*)a.rad_tmp, (const uint8_t*)a.rad_done, (const int32_t*)a.rad_arena,
                            (const int64_t*)a.rad_arena_off, d_offsets, d_idx);
-        if (brick_radius_usable<T>(ctx, a) && a.rad_tmp)
+        if ((brick_radius_usable<T>(ctx, a) && a.rad_tmp) || a.rad_dense)
             rc = launch_wave_radius_fill<T>(ctx, a, r, d_offsets, d_idx, a.fb_list, a.fb_count);
         else
             rc = launch_wave_radius_fill<T>(ctx, a, r, d_offsets, d_idx, nullptr, nullptr);

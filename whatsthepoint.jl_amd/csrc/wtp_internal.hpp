@@ -59,6 +59,9 @@ constexpr int kMaxAxisCells = 4096;
 constexpr int BX = 4, BY = 4, BZ = 4;
 constexpr int HX = BX + 2, HY = BY + 2, HZ = BZ + 2;
 constexpr int HCELLS = HX * HY * HZ;
+// RadiusTopology: a brick whose halo holds more points than this (~7.4 per cell) has rows beyond the lane-per-query
+// kernel's 32 entries (a row is ~4.06 cells' worth of points): it belongs to the dense kernel, or to the wave kernel
+constexpr int kRadDenseMin = 1600;
 constexpr int kBrickThreads = 256;
 // partial-reduction slots: [0, brick_partials()) brick blocks, then kWavePartials, then kGenericPartials
 constexpr int kWavePartials = 4096;    // wave-per-query kernel blocks
@@ -121,6 +124,8 @@ template <typename T> struct SearchArgs {
     int64_t* rad_arena_off;
     unsigned long long* rad_arena_pos;
     int64_t rad_arena_cap;
+    int32_t* rad_bricks;       // bricks listed for the dense kernel (at most one per point)
+    int32_t rad_dense;         // > 0: the brick-staged wave-per-query kernel (wtp_radb.hip) takes the bricks whose halo holds more than kRadDenseMin and at most this many points
     // fallback work list
     int32_t* fb_list;
     int32_t* fb_count;
@@ -278,6 +283,10 @@ struct wtp_ctx {
     wtp::DevBuf cand_idx, cand_dist, f32_pts; // fp64 topology: fp32 candidate lists and the float copy of the cloud
     wtp::DevBuf forces, nn_dist, nn_id, spacing_pp;
     wtp::DevBuf partials, stats, fb_list, fb_count, fb2_list, fb2_count, nn_list;
+    wtp::DevBuf rad_pos;           // counter block: [0, 8) next free id of the arena (wtp_radb.hip takes pieces of it), [8, 12) bricks listed
+    wtp::DevBuf rad_bricks;        // the dense kernel's brick list
+    bool rad_dense_attr[2] = {false, false}; // wtp_radb.hip: the kernel's LDS size has been declared (fp32, fp64)
+    bool rad_dense_used = false;   // the count phase ran the dense kernel: the fill phase's wave kernel works from the hand-back list
     wtp::DevBuf rad_tmp, rad_done; // RadiusTopology: rows parked by the count phase (32 ids per query), one byte per query
     wtp::DevBuf rad_arena, rad_arena_off; // ... and the wave kernel's rows (any length), their starts; the bump counter sits behind the starts
     wtp::DevBuf brick_dead;    // wtp_cs2.hip, variable spacing: one byte per brick (cs2_dead_kernel)
@@ -489,6 +498,8 @@ int relax_swap_commit(wtp_ctx* ctx, int64_t n_move_new);                   // ..
 int relax_set_fixed_dev_impl(wtp_ctx* ctx, const void* d_fixed4, int64_t n_fixed_new, bool keep_alive);
 int comm_exchange_peers_on(wtp_ctx* ctx, hipStream_t stream, int n_msgs, const int* peers, const void* const* d_send,
                            const int64_t* n_send, void* const* d_recv, const int64_t* n_recv); // wtp_comm.hip
+template <typename T> int launch_radius_dense(wtp_ctx* ctx, SearchArgs<T>& a, T r, int32_t* d_counts); // wtp_radb.hip
+template <typename T> int radius_dense_hcap();
 int relax_prerank(wtp_ctx* ctx, int64_t n_fixed_new); // first half of the next rebuild's hash, ahead of wtp_relax_set_fixed_dev (see wtp_api.hip)
 void block_destroy(wtp_ctx* ctx);                                          // frees ctx->block (wtp_destroy)
 template <typename T>

@@ -401,13 +401,13 @@ template <> struct RadSmem<double> {
 };
 
 template <typename T, bool FILL>
-__global__ __launch_bounds__(kThreads) void wave_radius_kernel(SearchArgs<T> a, T r, int32_t* __restrict__ counts,
+__global__ __launch_bounds__(kThreads, sizeof(T) == 4 ? 8 : 5) void wave_radius_kernel(SearchArgs<T> a, T r, int32_t* __restrict__ counts,
                                                                const int64_t* __restrict__ offsets,
                                                                int32_t* __restrict__ idx_out,
                                                                const int32_t* __restrict__ list,
                                                                const int32_t* __restrict__ list_count) {
     __shared__ RadSmem<T> sm_all[FILL ? kWaves : 1];
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // (uniform, and the compiler knows: the queries' chain of loads goes through the scalar unit)
     const int lane = threadIdx.x & 63;
     RadSmem<T>* sm = &sm_all[FILL ? wave : 0];
     const Grid<T> g = *a.grid;
@@ -415,28 +415,58 @@ __global__ __launch_bounds__(kThreads) void wave_radius_kernel(SearchArgs<T> a, 
     const int wave_global = blockIdx.x * kWaves + wave;
     const int wave_stride = gridDim.x * kWaves;
     // list: the queries the brick kernel handed back — unless the grid says that kernel stood aside (rad_wave_only)
-    const bool all = !list || g.rad_wave_only;
+    const bool all = !list || (g.rad_wave_only && !a.rad_dense); // (with the dense kernel in front the list is what is left in either case)
     const int nq = all ? a.n : *list_count;
     const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     int64_t arena_used = 0; // ids this wave has parked in its share of the arena (count phase with ranking)
-    for (int qi = wave_global; qi < nq; qi += wave_stride) {
-        const int slot = all ? qi : list[qi];
-        const Pt<T> q = a.snap[slot];
-        const int32_t id = w_to_id(q.w);
-        // fill phase proper (counts == nullptr): a row the count phase ranked and parked in the arena is copied, not searched again
-        if (FILL && !counts && a.rad_done && a.rad_done[id] == 2) continue;
-        const int cx = cell_coord(g, q.x, 0), cy = cell_coord(g, q.y, 1), cz = cell_coord(g, q.z, 2);
+    // A query is a chain of dependent round trips (list -> point -> row bounds -> candidates [-> row offset]) and the CU is
+    // full of such waves, so a wave's time is the sum of its chains.  The chain is software-pipelined across the wave's
+    // queries: while query i is scanned, the row bounds of query i + 1, the point of query i + 2 and the list entry of
+    // query i + 3 are in flight; what stays exposed per query is the candidates' round trip.
+    auto slot_of = [&](int qi) { return qi < nq ? (all ? qi : list[qi]) : 0; };
+    // lanes 0 .. 8: the bounds of one x-row each of the 3 x 3 rows around p (absent rows: empty)
+    auto row_bounds = [&](const Pt<T>& p, bool on, int& b_ps, int& b_pe) {
+        const int cx = cell_coord(g, p.x, 0), cy = cell_coord(g, p.y, 1), cz = cell_coord(g, p.z, 2);
         const int z0 = cz - 1 < 0 ? 0 : cz - 1, z1 = cz + 1 > g.n[2] - 1 ? g.n[2] - 1 : cz + 1;
         const int y0 = cy - 1 < 0 ? 0 : cy - 1, y1 = cy + 1 > g.n[1] - 1 ? g.n[1] - 1 : cy + 1;
         const int x0 = cx - 1 < 0 ? 0 : cx - 1, x1 = cx + 1 > g.n[0] - 1 ? g.n[0] - 1 : cx + 1;
-        // lanes 0 .. 8: the bounds of one x-row each (absent rows: empty)
         const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
-        int my_ps = 0, my_pe = 0;
-        if (lane < nrows) {
+        b_ps = 0;
+        b_pe = 0;
+        if (on && lane < nrows) {
             const int row = ((z0 + lane / ny) * g.n[1] + (y0 + lane % ny)) * g.n[0];
-            my_ps = a.cell_start[row + x0];
-            my_pe = a.cell_start[row + x1 + 1];
+            b_ps = a.cell_start[row + x0];
+            b_pe = a.cell_start[row + x1 + 1];
         }
+    };
+    int qi = wave_global;
+    int slot0 = slot_of(qi), slot1 = slot_of(qi + wave_stride), slot2 = slot_of(qi + 2 * wave_stride);
+    Pt<T> q0 = a.snap[slot0], q1 = a.snap[slot1];
+    int b0_ps, b0_pe;
+    row_bounds(q0, qi < nq, b0_ps, b0_pe);
+    for (; qi < nq; qi += wave_stride) {
+        const int slot = slot0;
+        const Pt<T> q = q0;
+        asm volatile("" : "+v"(b0_ps), "+v"(b0_pe)); // (what is derived from the bounds stays inside this iteration: nine row addresses carried around the loop are 18 registers)
+        const int my_ps = b0_ps, my_pe = b0_pe;
+        const int32_t id = w_to_id(q.w);
+        // fill phase proper (counts == nullptr): a row the count phase ranked and parked in the arena is copied, not searched
+        // again (such rows exist only where this kernel serves every query); the row's place in the CSR array is asked for now
+        int done = 0;
+        if (FILL && !counts && all && a.rad_done) done = a.rad_done[id];
+        int64_t off_lo = 0, off_hi = 0;
+        if (FILL && !counts) {
+            off_lo = offsets[id];
+            off_hi = offsets[id + 1];
+        }
+        // the stages behind this query move up one step
+        row_bounds(q1, qi + wave_stride < nq, b0_ps, b0_pe);
+        slot0 = slot1;
+        q0 = q1;
+        slot1 = slot2;
+        q1 = a.snap[slot2];
+        slot2 = slot_of(qi + 3 * wave_stride);
+        if (done == 2) continue;
         int ps[9], len[9];
         Pt<T> c[9];
 #pragma unroll
@@ -445,8 +475,12 @@ __global__ __launch_bounds__(kThreads) void wave_radius_kernel(SearchArgs<T> a, 
             len[rr] = __builtin_amdgcn_readlane(my_pe, rr) - ps[rr];
         }
 #pragma unroll
-        for (int rr = 0; rr < 9; ++rr) // the first 64 points of every row: nine loads in flight
-            if (lane < len[rr]) c[rr] = a.snap[ps[rr] + lane];
+        for (int rr = 0; rr < 9; ++rr) { // the first 64 points of every row: nine loads in flight
+            // (every lane loads — those past the row's end its last point again, masked out below: a load under a lane mask
+            // leaves the other lanes' registers undefined, and the compiler then carried them around the loop)
+            const int last = len[rr] - 1;
+            c[rr] = a.snap[ps[rr] + (len[rr] > 0 ? (lane < last ? lane : last) : 0)];
+        }
         int m = 0;
         auto visit = [&](const Pt<T>& cc, bool on) {
             bool take = false;
@@ -478,7 +512,9 @@ __global__ __launch_bounds__(kThreads) void wave_radius_kernel(SearchArgs<T> a, 
             for (int p0 = 64; p0 < len[rr]; p0 += 64) { // rows beyond 64 points (dense clusters)
                 const bool on = p0 + lane < len[rr];
                 Pt<T> cc{};
-                if (on) cc = a.snap[ps[rr] + p0 + lane];
+                int first = ps[rr] + p0;
+                asm volatile("" : "+s"(first)); // (its own address arithmetic: nine row addresses kept alive for this loop cost 18 registers)
+                if (on) cc = a.snap[first + lane];
                 visit(cc, on);
             }
         }
@@ -516,31 +552,27 @@ __global__ __launch_bounds__(kThreads) void wave_radius_kernel(SearchArgs<T> a, 
                 a.rad_done[id] = 2;
             }
         } else {
-            base = offsets[id];
-            cap = offsets[id + 1] - base;
+            base = off_lo;
+            cap = off_hi - off_lo;
         }
         if constexpr (sizeof(T) == 4) {
             // every lane ranks the (up to four) entries it owns against all m keys, two keys per LDS read
             if (lane == 0) sm->key[m] = ~0ull; // an odd m reads one key past the end
             __builtin_amdgcn_wave_barrier();
-            unsigned long long mine[kRadOwn];
-            int rank[kRadOwn];
-#pragma unroll
-            for (int o = 0; o < kRadOwn; ++o) {
-                mine[o] = lane + 64 * o < m ? sm->key[lane + 64 * o] : 0ull;
-                rank[o] = 0;
-            }
-            const int owned = (m + 63) / 64; // (wave-uniform)
-            for (int j = 0; j < m; j += 2) {
-                const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(&sm->key[j]);
-#pragma unroll
-                for (int o = 0; o < kRadOwn; ++o) {
-                    if (o < owned) rank[o] += (kk.x < mine[o] ? 1 : 0) + (kk.y < mine[o] ? 1 : 0);
+            // (two owned entries per pass over the keys: rows of up to 128 entries take one pass, and the registers stay few)
+#pragma unroll 1
+            for (int o0 = 0; o0 < m; o0 += 128) {
+                const int e0 = o0 + lane, e1 = o0 + 64 + lane;
+                const unsigned long long mine0 = e0 < m ? sm->key[e0] : 0ull, mine1 = e1 < m ? sm->key[e1] : 0ull;
+                int rank0 = 0, rank1 = 0;
+                for (int j = 0; j < m; j += 2) {
+                    const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(&sm->key[j]);
+                    rank0 += (kk.x < mine0 ? 1 : 0) + (kk.y < mine0 ? 1 : 0);
+                    rank1 += (kk.x < mine1 ? 1 : 0) + (kk.y < mine1 ? 1 : 0);
                 }
+                if (e0 < m && rank0 < cap) idx_out[base + rank0] = (int32_t)(uint32_t)mine0;
+                if (e1 < m && rank1 < cap) idx_out[base + rank1] = (int32_t)(uint32_t)mine1;
             }
-#pragma unroll
-            for (int o = 0; o < kRadOwn; ++o)
-                if (lane + 64 * o < m && rank[o] < cap) idx_out[base + rank[o]] = (int32_t)(uint32_t)mine[o];
         } else {
             const RadSmem<double>* sd = reinterpret_cast<const RadSmem<double>*>(sm);
             for (int i = lane; i < m; i += 64) {
