@@ -247,22 +247,41 @@ template <> int brick_radius<float>(wtp_ctx* ctx, SearchArgs<float>& a) { return
 __global__ void radius_copy_rows_kernel(int64_t n, const int32_t* __restrict__ tmp, const uint8_t* __restrict__ done,
                                         const int32_t* __restrict__ arena, const int64_t* __restrict__ arena_off,
                                         const int64_t* __restrict__ offsets, int32_t* __restrict__ idx) {
-    // sixteen lanes per row: rows of the wave kernel's arena run to hundreds of ids
+    // sixteen lanes per row: rows of the wave kernel's arena run to hundreds of ids.  A row is a chain (mark -> offsets and
+    // place in the arena -> ids), and the kernel's time was the sum of those chains: the marks and offsets of the group's
+    // NEXT row are asked for before this row's ids are copied.
     const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4, ngrp = ((int64_t)gridDim.x * blockDim.x) >> 4;
     const int l = threadIdx.x & 15;
-    for (int64_t q = grp; q < n; q += ngrp) {
-        const uint8_t d = done[q];
-        if (!d) continue;
-        const int64_t o = offsets[q];
-        int64_t len = offsets[q + 1] - o;
-        const int32_t* row;
-        if (d == 1) {
-            row = tmp + q * 32;
-            len = len > 32 ? 32 : len;
-        } else {
-            row = arena + arena_off[q];
+    auto meta = [&](int64_t q, uint8_t& d, int64_t& o, int64_t& len, int64_t& ao) {
+        d = 0;
+        o = len = ao = 0;
+        if (q < n) {
+            d = done[q];
+            o = offsets[q];
+            len = offsets[q + 1] - o;
+            ao = arena_off ? arena_off[q] : 0; // (read for every row: waiting for the mark first is the chain this avoids)
         }
-        for (int64_t j = l; j < len; j += 16) idx[o + j] = row[j];
+    };
+    uint8_t d, dn;
+    int64_t o, len, ao, on, lenn, aon;
+    meta(grp, d, o, len, ao);
+    for (int64_t q = grp; q < n; q += ngrp) {
+        meta(q + ngrp, dn, on, lenn, aon);
+        if (d) {
+            const int32_t* row;
+            int64_t cnt = len;
+            if (d == 1) {
+                row = tmp + q * 32;
+                cnt = cnt > 32 ? 32 : cnt;
+            } else {
+                row = arena + ao;
+            }
+            for (int64_t j = l; j < cnt; j += 16) idx[o + j] = row[j];
+        }
+        d = dn;
+        o = on;
+        len = lenn;
+        ao = aon;
     }
 }
 
