@@ -656,6 +656,7 @@ WTP_API int wtp_create(const int* device_ordinals, int n_dev, wtp_ctx** out) {
     if (const char* e = getenv("WTP_FULL_SELECT")) ctx->full_select = atoi(e);
     if (const char* e = getenv("WTP_CS2")) ctx->cs2 = atoi(e);
     if (const char* e = getenv("WTP_KSEL")) ctx->ksel = atoi(e);
+    if (const char* e = getenv("WTP_F64_KSEL")) ctx->f64_ksel = atoi(e);
     if (const char* e = getenv("WTP_RHO_KSEL")) ctx->rho_ksel = atof(e) > 0 ? atof(e) : ctx->rho_ksel;
     if (const char* e = getenv("WTP_CAP_KSEL")) ctx->cap_ksel = atof(e) > 0 ? atof(e) : ctx->cap_ksel;
     if (const char* e = getenv("WTP_RHO_CS")) ctx->rho_cs2 = atof(e) >= 1.0 ? atof(e) : ctx->rho_cs2;
@@ -680,7 +681,7 @@ WTP_API int wtp_destroy(wtp_ctx* ctx) {
                       &ctx->cell_cnt, &ctx->cell_start, &ctx->scan_tmp, &ctx->grid, &ctx->bbox_part,
                       &ctx->idx_out, &ctx->dist_out, &ctx->counts_out, &ctx->forces, &ctx->nn_dist,
                       &ctx->nn_id, &ctx->spacing_pp, &ctx->partials, &ctx->stats, &ctx->fb_list,
-                      &ctx->fb_count, &ctx->fb2_list, &ctx->fb2_count, &ctx->nn_list, &ctx->brick_dead, &ctx->rad_tmp, &ctx->rad_done, &ctx->rad_arena, &ctx->rad_arena_off, &ctx->rad_pos, &ctx->rad_bricks, &ctx->scratch, &ctx->diag,
+                      &ctx->fb_count, &ctx->fb2_list, &ctx->fb2_count, &ctx->nn_list, &ctx->brick_dead, &ctx->rad_tmp, &ctx->rad_done, &ctx->rad_arena, &ctx->rad_arena_off, &ctx->rad_pos, &ctx->rad_bricks, &ctx->grid_b, &ctx->cell_start_b, &ctx->f64k_s64, &ctx->f64k_slot, &ctx->f64k_lists, &ctx->f64k_cnt, &ctx->scratch, &ctx->diag,
                       &ctx->ins_in, &ctx->ins_elems, &ctx->ins_partial, &ctx->ins_out, &ctx->mesh_nodes, &ctx->mesh_pn, &ctx->mesh_io,
                       &ctx->wall_flags, &ctx->wall_tri, &ctx->wall_hint, &ctx->mesh_cls, &ctx->kd_nodes, &ctx->sp_hint, &ctx->occ, &ctx->box_dev,
                       &ctx->cand_idx, &ctx->cand_dist, &ctx->f32_pts, &ctx->comm_scratch, &ctx->sp_cert};
@@ -1273,6 +1274,102 @@ static int cs2_tune(wtp_ctx* ctx, RelaxState& r, const Grid<float>& hg, double r
     return WTP_OK;
 }
 
+// Float64 sweep of a k-nearest law on a fresh snapshot (wtp_sweep64.hip): candidates from the fp32 k-selection kernels on a
+// float copy of the snapshot with its own grid — the session's grid and cell table are parked meanwhile and come back
+// untouched for the exact path —, exact re-ranking + force sum + step per query, the wave kernel for what is not certified.
+static int relax_f64_ksel_sweep(wtp_ctx* ctx, SearchArgs<double>& a) {
+    RelaxState& r = ctx->relax;
+    const int64_t n = r.n;
+    const int kc = 24;
+    int rc;
+    if ((rc = ensure(ctx, ctx->f32_pts, 2 * sizeof(float4) * (size_t)n))) return rc;
+    if ((rc = ensure(ctx, ctx->cand_idx, sizeof(int32_t) * (size_t)n * kc))) return rc;
+    if ((rc = ensure(ctx, ctx->cand_dist, sizeof(float) * (size_t)n * kc))) return rc;
+    if ((rc = ensure(ctx, ctx->f64k_s64, sizeof(double4) * (size_t)n))) return rc;
+    if ((rc = ensure(ctx, ctx->f64k_slot, sizeof(int32_t) * (size_t)n))) return rc;
+    if ((rc = ensure(ctx, ctx->f64k_lists, sizeof(int32_t) * 2 * (size_t)n))) return rc;
+    if ((rc = ensure(ctx, ctx->f64k_cnt, 64))) return rc;
+    if ((rc = ensure(ctx, ctx->occ, 64))) return rc;
+    const double4* snap = (const double4*)a.snap; // the sorted snapshot (fresh: the queries are its points)
+    float4* raw32 = (float4*)ctx->f32_pts.p;
+    float4* sorted32 = raw32 + n;
+    double* org4 = (double*)ctx->occ.p + 4; // behind the occupancy counters
+    int sp = span_begin(ctx, 0);
+    if ((rc = launch_origin(ctx, snap, n, org4))) return rc;
+    if ((rc = launch_f64k_local(ctx, snap, n, org4, raw32))) return rc;
+    std::swap(ctx->grid, ctx->grid_b);
+    std::swap(ctx->cell_start, ctx->cell_start_b);
+    const void* ncells_session = ctx->ncells_dev;
+    const bool box_session = ctx->box_active;
+    ctx->box_active = false; // (a clipped box is in the session's coordinates)
+    ctx->topology_build = true; // rows are ordered explicitly: no canonical-order pass
+    const bool tuned = r.f64k_n > 0 && std::llabs((long long)(n - r.f64k_n)) * 20 <= (long long)n;
+    if (tuned) {
+        rc = build_hash<float>(ctx, raw32, sorted32, n, 3, kc, 0.0, r.f64k_rho, 0.0, r.f64k_scale);
+    } else { // once per session: cell scale and occupancy measured on the float copy (host reads)
+        double scale = 1.0, rho_eff = 0, rho_direct = ksel_rho_for(ctx, kc);
+        Grid<float> hg;
+        rc = build_hash_tuned<float>(ctx, raw32, sorted32, n, 3, kc, 0.0, rho_direct, 0.0, &scale, &rho_eff, &hg);
+        if (!rc) {
+            const double pick = ksel_pick_rho(ctx, (double)n, (double)hg.ncells, hg.n[0], rho_direct, rho_eff);
+            if (std::fabs(pick - rho_direct) > 0.01 * rho_direct) {
+                rho_direct = pick;
+                scale = 1.0;
+                rc = build_hash_tuned<float>(ctx, raw32, sorted32, n, 3, kc, 0.0, rho_direct, 0.0, &scale, &rho_eff, &hg);
+            }
+        }
+        if (!rc) {
+            r.f64k_n = n;
+            r.f64k_scale = scale;
+            r.f64k_rho = rho_direct;
+            ksel_geometry(ctx, (double)n, (double)hg.ncells, hg.n[0], rho_eff, &r.f64k_bx, &r.f64k_hcap);
+        }
+    }
+    ctx->topology_build = false;
+    if (!rc) rc = launch_f64k_relabel(ctx, snap, sorted32, (int32_t*)ctx->f64k_slot.p, (double4*)ctx->f64k_s64.p, n);
+    span_end(ctx, sp);
+    sp = span_begin(ctx, 1);
+    if (!rc) {
+        SearchArgs<float> b{};
+        b.grid = (const Grid<float>*)ctx->grid.p;
+        b.snap = sorted32;
+        b.query = sorted32;
+        b.cell_start = (const int32_t*)ctx->cell_start.p;
+        b.n = (int32_t)n;
+        b.k = kc;
+        b.include_self = 1;
+        b.idx_out = (int32_t*)ctx->cand_idx.p;
+        b.dist_out = (float*)ctx->cand_dist.p;
+        b.fb_list = (int32_t*)ctx->f64k_lists.p;
+        b.fb_count = (int32_t*)ctx->f64k_cnt.p;
+        b.fb2_list = (int32_t*)ctx->f64k_lists.p + n;
+        b.fb2_count = (int32_t*)ctx->f64k_cnt.p + 4;
+        b.stop = ctx->stop_dev;
+        b.diag = a.diag;
+        b.ksel_bx = r.f64k_bx;
+        b.brick_hcap = r.f64k_hcap;
+        b.cap_count = (float)ksel_cap_count(ctx, kc);
+        WTP_HIP(ctx, hipMemsetAsync(ctx->f64k_cnt.p, 0, 64, ctx->stream));
+        b.counters_cleared = 1;
+        rc = launch_topology<float>(ctx, b);
+    }
+    // the session's structures again (the float copy's stay where they are until the next sweep overwrites them)
+    std::swap(ctx->grid, ctx->grid_b);
+    std::swap(ctx->cell_start, ctx->cell_start_b);
+    ctx->ncells_dev = ncells_session;
+    ctx->box_active = box_session;
+    if (rc) return rc;
+    ctx->n_sweep_launches += 1;
+    rc = launch_refine_sweep_f64(ctx, a, (const double4*)ctx->f64k_s64.p, (const int32_t*)ctx->f64k_slot.p,
+                                 (const int32_t*)ctx->cand_idx.p, (const float*)ctx->cand_dist.p, org4);
+    span_end(ctx, sp);
+    if (rc) return rc;
+    sp = span_begin(ctx, 2);
+    rc = launch_generic_sweep<double>(ctx, a, false); // the exact path for what the certificate turned down
+    span_end(ctx, sp);
+    return rc;
+}
+
 template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_step_stats* d_slot) {
     RelaxState& r = ctx->relax;
     int rc;
@@ -1472,7 +1569,14 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
     if (!ctx->counters_clean) WTP_HIP(ctx, hipMemsetAsync(ctx->fb_count.p, 0, 64, ctx->stream));
     ctx->counters_clean = false; // (set again by the step's final reduction, which zeroes the block after reading it)
     a.used_brick = a.used_wave = a.used_generic = 0;
-    if ((rc = launch_sweep<T>(ctx, a, fresh))) return rc;
+    bool by_candidates = false;
+    if constexpr (sizeof(T) == 8) {
+        // the k-nearest laws in Float64 on a fresh snapshot: fp32 candidates, exact re-ranking (wtp_sweep64.hip)
+        by_candidates = fresh && r.dim == 3 && ctx->ksel && ctx->f64_ksel && !ctx->force_generic &&
+                        r.force.kind != WTP_FORCE_CLIPPED_SPACING && r.k >= 2 && r.k <= 22 && r.n >= 4096;
+        if (by_candidates && (rc = relax_f64_ksel_sweep(ctx, a))) return rc;
+    }
+    if (!by_candidates && (rc = launch_sweep<T>(ctx, a, fresh))) return rc;
     int sp = span_begin(ctx, 2);
     if (r.wall_active) { // p[id] = constrain(id, x_i, x_i + disp) (src/repel.jl:290): the octree wall rule
         char* wf = (char*)ctx->wall_flags.p;

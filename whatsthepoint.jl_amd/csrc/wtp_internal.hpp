@@ -220,6 +220,10 @@ struct RelaxState {
     int swap_target = -1;    // relax_swap_begin .. relax_swap_commit (wtp_block.hip: migration)
     bool shard_grid_reuse = false; // block sessions: the grid is kept across a swapped ghost head (points outside it pile into edge cells, which every search treats as unbounded outward)
     int64_t grid_fixed = -1;       // fixed points the current grid's bounding box was computed with
+    // fp64 sweeps through fp32 candidates: what the float copy's grid was measured with (cloud size, cell scale, occupancy, brick geometry)
+    int64_t f64k_n = 0;
+    double f64k_scale = 1.0, f64k_rho = 0.0;
+    int f64k_bx = 0, f64k_hcap = 0;
     double last_rho_cs = 0.0;      // occupancy argument of the session's last hash build (relax_prerank sizes its scratch alike)
     bool wall_active = false; // octree method: _constrain_octree runs after every sweep (wtp_relax_set_wall)
     double wall_offset = 0;   // inward nudge of a projected boundary point (src/repel.jl:143)
@@ -281,6 +285,10 @@ struct wtp_ctx {
     const void* ncells_dev = nullptr; // device address of Grid::ncells of the last build_hash
     wtp::DevBuf idx_out, dist_out, counts_out;
     wtp::DevBuf cand_idx, cand_dist, f32_pts; // fp64 topology: fp32 candidate lists and the float copy of the cloud
+    // fp64 sweeps through fp32 candidates (wtp_sweep64.hip): the session's grid and cell table parked while the float copy's
+    // are built and searched; the fp64 points and their session slots in the float copy's order; the search's own lists
+    wtp::DevBuf grid_b, cell_start_b, f64k_s64, f64k_slot, f64k_lists, f64k_cnt;
+    int f64_ksel = 1;                         // WTP_F64_KSEL=0: the exact wave-per-query path for those sweeps
     wtp::DevBuf forces, nn_dist, nn_id, spacing_pp;
     wtp::DevBuf partials, stats, fb_list, fb_count, fb2_list, fb2_count, nn_list;
     wtp::DevBuf rad_pos;           // counter block: [0, 8) next free id of the arena (wtp_radb.hip takes pieces of it), [8, 12) bricks listed
@@ -465,6 +473,11 @@ int launch_spacing_session(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int64_t fi
                            const int32_t* d_cell_start = nullptr, const void* d_grid = nullptr, void* d_cert = nullptr);
 // fp64 topology through an fp32 candidate search (wtp_hash.hip)
 int launch_origin(wtp_ctx* ctx, const double4* pts, int64_t n, double* d_org4);
+// wtp_sweep64.hip: fp64 sweeps of the k-nearest laws through fp32 candidates
+int launch_f64k_local(wtp_ctx* ctx, const double4* snap, int64_t n, const double* d_org4, float4* out);
+int launch_f64k_relabel(wtp_ctx* ctx, const double4* snap, float4* sorted32, int32_t* sslot, double4* s64, int64_t n);
+int launch_refine_sweep_f64(wtp_ctx* ctx, SearchArgs<double>& a, const double4* s64, const int32_t* sslot, const int32_t* cand,
+                            const float* cdist, const double* d_org4);
 int launch_to_local_f32(wtp_ctx* ctx, const double4* in, int64_t n, const double* d_org4, float4* out);
 int launch_refine_f64(wtp_ctx* ctx, const double4* raw, const int32_t* cand, const float* cdist, int64_t n, int kc, int k,
                       int include_self, const double* d_org4, int32_t* idx_out, double* dist_out, int32_t* fail_list,

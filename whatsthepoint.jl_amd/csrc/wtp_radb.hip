@@ -171,8 +171,7 @@ __global__ __launch_bounds__(kRdThreads, 8) void rad_dense_kernel(SearchArgs<T> 
     const Grid<T> g = *a.grid;
     const int dense_min = (sizeof(T) == 8 || g.rad_wave_only) ? -1 : kRadDenseMin; // fp32: below it the brick kernel has served the brick
     const T r2 = r * r; // inclusive, compared as d2 <= r*r
-    const int nbx = (g.n[0] + G::bx - 1) / G::bx, nby = (g.n[1] + G::by - 1) / G::by, nbz = (g.n[2] + G::bz - 1) / G::bz;
-    const int nbricks = nbx * nby * nbz;
+    const int nbx = (g.n[0] + G::bx - 1) / G::bx, nby = (g.n[1] + G::by - 1) / G::by;
     const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     int64_t chunk_base = 0;
     int chunk_left = 0; // ids left in the wave's current piece of the arena

@@ -390,7 +390,6 @@ __global__ __launch_bounds__(kThreads) void wave_kernel(SearchArgs<T> a, const i
 // key per entry, (d2 bits << 32 | id) — monotone in (d2, id) because d2 >= 0 — two keys per LDS read, every lane ranking
 // all the entries it owns in the same pass.  Graded 1 M-point cloud, rows of ~65: fill 3.0 -> see DESIGN.md §4.
 constexpr int kRadCap = 512;  // entries a wave ranks in LDS; longer rows: the serial kernel
-constexpr int kRadOwn = kRadCap / 64;
 template <typename T> struct RadSmem;
 template <> struct RadSmem<float> {
     unsigned long long key[kRadCap + 2];
