@@ -207,6 +207,18 @@ def other_paths(ctx, torch, np, wtp_amd, extra_legs=False, e2e=True):
         dt = (time.perf_counter() - t0) / 10
     out["repel_f64_4M"] = {"value": round(n64 / dt / 1e6, 1), "unit": "Mpoints/s", "ms_per_iter": round(dt * 1e3, 3),
                            "note": "Float64 cloud, ClippedSpacingForce: brick_cs_kernel<double> (sums in ascending (d2, id) order)"}
+    # the same cloud with a law that needs the explicit k nearest (SpacingEquilibriumForce): fp32 candidates from the
+    # k-selection kernels, exact re-ranking + force sum per query (csrc/wtp_sweep64.hip), bit-identical to the exact path
+    with ctx.relax(x64, 0, s64, dict(kind=1, beta=0.2, u0=1.0, gamma=3.0), 21, s64 / 2000, s64 / 20) as t:
+        t.run_async_free(3, 1)
+        t0 = time.perf_counter()
+        _, st64 = t.run(10, 1)
+        dt = (time.perf_counter() - t0) / 10
+    out["repel_f64_4M_spacing_equilibrium"] = {
+        "value": round(n64 / dt / 1e6, 1), "unit": "Mpoints/s", "ms_per_iter": round(dt * 1e3, 3),
+        "exact_path_fraction": round(st64["n_fallback"] / n64, 6),
+        "note": "Float64 cloud, SpacingEquilibriumForce: ksel_kernel<0,24> on a float copy + refine_sweep_f64_kernel "
+                "(round 2 and most of round 3: the exact wave-per-query path alone, 137 Mpoints/s)"}
     del x64
     if not e2e:
         return out

@@ -1374,6 +1374,11 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
     RelaxState& r = ctx->relax;
     int rc;
     if (!r.have_tree || r.pending.active) rebuild = 1; // the reference builds its first tree in the setup (src/repel.jl:218)
+    // Float64, a k-nearest law, 3-D: on a fresh snapshot the sweep takes its candidates from the fp32 k-selection kernels
+    // (wtp_sweep64.hip).  Every sum on that route and on the exact path behind it is ordered by (d2, index) explicitly, so
+    // the snapshot's cells need no canonical order.
+    const bool f64k_ok = sizeof(T) == 8 && r.dim == 3 && ctx->ksel && ctx->f64_ksel && !ctx->force_generic &&
+                         r.force.kind != WTP_FORCE_CLIPPED_SPACING && r.k >= 2 && r.k <= 22 && r.n >= 4096;
     if (rebuild) {
         // snapshot tail <- p, tree rebuilt (src/repel.jl:245-253): scatter P into a free buffer
         const int t = pick_free(r, r.bufP, -1);
@@ -1479,8 +1484,10 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
             ctx->reuse_grid = reuse;
             r.grid_age = reuse ? r.grid_age + 1 : 0;
             if (!reuse) r.grid_fixed = r.n_fixed;
+            ctx->topology_build = f64k_ok; // (no canonical-order pass: 0.37 ms per 10 M Float64 points)
             rc = build_hash<T>(ctx, (const Pt<T>*)ctx->pts[r.bufP].p, (Pt<T>*)ctx->pts[t].p, r.n, r.dim, r.k, 0.0, rho_cs,
                                min_cell, r.cell_scale);
+            ctx->topology_build = false;
             ctx->reuse_grid = false;
         }
         r.last_rho_cs = rho_cs;
@@ -1572,8 +1579,7 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
     bool by_candidates = false;
     if constexpr (sizeof(T) == 8) {
         // the k-nearest laws in Float64 on a fresh snapshot: fp32 candidates, exact re-ranking (wtp_sweep64.hip)
-        by_candidates = fresh && r.dim == 3 && ctx->ksel && ctx->f64_ksel && !ctx->force_generic &&
-                        r.force.kind != WTP_FORCE_CLIPPED_SPACING && r.k >= 2 && r.k <= 22 && r.n >= 4096;
+        by_candidates = fresh && f64k_ok;
         if (by_candidates && (rc = relax_f64_ksel_sweep(ctx, a))) return rc;
     }
     if (!by_candidates && (rc = launch_sweep<T>(ctx, a, fresh))) return rc;
