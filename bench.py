@@ -320,7 +320,21 @@ def _graded_legs(out, ctx, np, wtp_amd, time, torch):
     # graded cloud (BASELINE config 5 / north star "uniform and graded clouds"): thinned uniform stream,
     # h_bulk/h_wall = 4 (64x density contrast), 10 M points, with its own BoundaryLayerSpacing law evaluated on the device
     ng = 10_000_000
-    xg = graded_dev(ctx, torch, np, wtp_amd, ng).cpu().numpy()
+    xg_dev = graded_dev(ctx, torch, np, wtp_amd, ng)
+    xg = xg_dev.cpu().numpy()
+    # KNNTopology on the graded cloud (device-resident call, like the uniform 1 M leg)
+    gidx = torch.empty((ng, 21), dtype=torch.int32, device="cuda")
+    ctx.knn_dev(xg_dev.data_ptr(), ng, 3, np.float32, 21, False, gidx.data_ptr())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.knn_dev(xg_dev.data_ptr(), ng, 3, np.float32, 21, False, gidx.data_ptr())
+    torch.cuda.synchronize()
+    dtk = time.perf_counter() - t0
+    out["graded_knn_topology_k21_10M"] = {
+        "value": round(ng / dtk / 1e6, 1), "unit": "Mpoints/s", "ms": round(dtk * 1e3, 3),
+        "note": "64x density contrast: the k-selection grid is sized by the dense part and hands half of the queries to the "
+                "exact wave-per-query path (DESIGN.md section 9, item 2e); uniform cloud: knn_topology_k21_1M"}
+    del gidx, xg_dev
     shell = int((np.minimum(xg, 1 - xg).min(axis=1) < 0.02).sum())
     hw = float(((1 - 0.96 ** 3) / shell) ** (1.0 / 3.0))
     mg = int(1 / hw)
