@@ -276,7 +276,14 @@ __global__ void radius_copy_rows_kernel(int64_t n, const int32_t* __restrict__ t
             } else {
                 row = arena + ao;
             }
-            for (int64_t j = l; j < cnt; j += 16) idx[o + j] = row[j];
+            for (int64_t j0 = l; j0 < cnt; j0 += 64) { // four loads of the row in flight, then the four stores
+                int32_t v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = j0 + 16 * u < cnt ? row[j0 + 16 * u] : 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (j0 + 16 * u < cnt) idx[o + j0 + 16 * u] = v[u];
+            }
         }
         d = dn;
         o = on;

@@ -280,7 +280,11 @@ __global__ __launch_bounds__(kRdThreads, 8) void rad_dense_kernel(SearchArgs<T> 
         }
         __syncthreads();
         // ---- 4. one wave per query ---------------------------------------------------------------------------------------
-        for (int q = wave; q < Q; q += kRdWaves) {
+        // (a wave takes CONSECUTIVE queries: their rows then sit next to each other in its piece of the arena, in the order the
+        // copy pass reads them)
+        const int per_wave = (Q + kRdWaves - 1) / kRdWaves;
+        const int q_end = (wave + 1) * per_wave < Q ? (wave + 1) * per_wave : Q;
+        for (int q = wave * per_wave; q < q_end; ++q) {
             int rr;
             {
                 const bool le = lane >= 1 && lane < OR && sm->own_pref[lane < OR ? lane : 0] <= q;
