@@ -84,3 +84,46 @@ def test_sweep_on_graded_cloud_with_its_spacing_law(O, wtp, ctx, n):
     assert err.max() < 1e-4 and np.quantile(err, 0.999) < 1e-5
     assert st["n_move"] == n and 0 < st["n_fallback"] < 0.5 * n      # the coarse region takes the exact path
     assert abs(st["max_force"] - float(r["forces"].max())) <= 1e-4 * float(r["forces"].max())
+
+
+def test_float64_sweep_on_graded_cloud_bit_exact_with_and_without_the_ball_kernel(O, wtp, monkeypatch):
+    """Float64, ClippedSpacingForce, BoundaryLayerSpacing on the device: the queries whose support is wider than their cell
+    take csrc/wtp_ball64.hip (eight lanes per query, the ball's points ranked and added in (d2, index) order) instead of the
+    wave-per-query path — same positions to the last bit, and equal to the oracle's sequential evaluation."""
+    n = 120_000
+    x = wtp.synth.graded(n, 4.0, 0.2, np.float64)
+    shell = (np.minimum(x, 1 - x).min(axis=1) < 0.02).sum()
+    hw = float(((1 - 0.96 ** 3) / shell) ** (1 / 3))
+    m = int(1 / hw)
+    g = (np.arange(m, dtype=np.float64) + 0.5) / m
+    u, v = np.meshgrid(g, g, indexing="ij")
+    faces = []
+    for axis in range(3):
+        for side in (0.0, 1.0):
+            c = np.zeros((m * m, 3), np.float64)
+            c[:, axis] = side
+            c[:, (axis + 1) % 3] = u.ravel()
+            c[:, (axis + 2) % 3] = v.ravel()
+            faces.append(c)
+    b = np.concatenate(faces)
+    law = wtp.BoundaryLayerSpacing(b, at_wall=hw, bulk=4 * hw, layer_thickness=0.2)
+    snap = np.concatenate([b, x])
+    force = dict(kind=2, beta=0.2, u0=1.0, gamma=3.0)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("WTP_BALL64", flag)
+        with wtp.Context(0) as c:
+            with c.relax(snap, len(b), law.desc(), force, 21, hw / 2000, hw / 20) as t:
+                st = [t.step(True) for _ in range(3)]
+                res[flag] = (t.positions(), t.point_data(), st, t.spacings())
+    assert np.array_equal(res["1"][0], res["0"][0])
+    assert np.array_equal(res["1"][1]["forces"], res["0"][1]["forces"]) and np.array_equal(res["1"][1]["nn_id"], res["0"][1]["nn_id"])
+    assert res["1"][2][0]["n_fallback"] < res["0"][2][0]["n_fallback"] // 4, "the ball kernel finishes most of the hand-backs"
+    assert res["1"][2][-1]["max_force"] == res["0"][2][-1]["max_force"]
+    # one sweep against the oracle (its spacings are the device's, checked elsewhere)
+    with wtp.Context(0) as c:
+        with c.relax(snap, len(b), law.desc(), force, 21, hw / 2000, hw / 20) as t:
+            t.step(True)
+            got, sp = t.positions(), t.spacings()
+    r = O.relax_sweep(snap, len(b), sp, 2, 0.2, 1.0, 3.0, 21, hw / 2000, hw / 20)
+    assert np.array_equal(got, r["p"])

@@ -657,6 +657,7 @@ WTP_API int wtp_create(const int* device_ordinals, int n_dev, wtp_ctx** out) {
     if (const char* e = getenv("WTP_CS2")) ctx->cs2 = atoi(e);
     if (const char* e = getenv("WTP_KSEL")) ctx->ksel = atoi(e);
     if (const char* e = getenv("WTP_F64_KSEL")) ctx->f64_ksel = atoi(e);
+    if (const char* e = getenv("WTP_BALL64")) ctx->ball64 = atoi(e);
     if (const char* e = getenv("WTP_RHO_KSEL")) ctx->rho_ksel = atof(e) > 0 ? atof(e) : ctx->rho_ksel;
     if (const char* e = getenv("WTP_CAP_KSEL")) ctx->cap_ksel = atof(e) > 0 ? atof(e) : ctx->cap_ksel;
     if (const char* e = getenv("WTP_RHO_CS")) ctx->rho_cs2 = atof(e) >= 1.0 ? atof(e) : ctx->rho_cs2;
@@ -1556,6 +1557,11 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
         a.nn_list = (int32_t*)ctx->nn_list.p;
     }
     if (ball) { // the follow-up kernel has consumed the list by the time the ball kernel refills it
+        a.ball_list = (int32_t*)ctx->nn_list.p;
+        a.ball_count = (int32_t*)ctx->fb_count.p + 6;
+    }
+    if (r.cs_sweep && sizeof(T) == 8 && r.spacing_kind != WTP_SPACING_CONSTANT && ctx->ball64) { // wtp_ball64.hip: its Float64 twin
+        if ((rc = ensure(ctx, ctx->nn_list, sizeof(int32_t) * (size_t)r.n))) return rc;
         a.ball_list = (int32_t*)ctx->nn_list.p;
         a.ball_count = (int32_t*)ctx->fb_count.p + 6;
     }

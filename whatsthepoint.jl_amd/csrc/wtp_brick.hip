@@ -1028,6 +1028,8 @@ template <> int launch_sweep<double>(wtp_ctx* ctx, SearchArgs<double>& a, bool f
     a.gamma_cap = ctx->gamma_cap;
     const int sp = span_begin(ctx, 1);
     int rc = launch_brick_cs<double>(ctx, a);
+    // variable spacing: the hand-backs whose support ball is wider than a cell (wtp_ball64.hip), before the exact path
+    if (!rc && a.spacing_pp && a.ball_list) rc = launch_cs_ball64(ctx, a, a.ball_list, a.ball_count);
     span_end(ctx, sp);
     if (rc) return rc;
     const int sp2 = span_begin(ctx, 2);

@@ -288,6 +288,7 @@ struct wtp_ctx {
     // fp64 sweeps through fp32 candidates (wtp_sweep64.hip): the session's grid and cell table parked while the float copy's
     // are built and searched; the fp64 points and their session slots in the float copy's order; the search's own lists
     wtp::DevBuf grid_b, cell_start_b, f64k_s64, f64k_slot, f64k_lists, f64k_cnt;
+    int ball64 = 1;                           // WTP_BALL64=0: Float64 variable-spacing hand-backs straight to the wave kernel
     int f64_ksel = 1;                         // WTP_F64_KSEL=0: the exact wave-per-query path for those sweeps
     wtp::DevBuf forces, nn_dist, nn_id, spacing_pp;
     wtp::DevBuf partials, stats, fb_list, fb_count, fb2_list, fb2_count, nn_list;
@@ -513,6 +514,7 @@ int comm_exchange_peers_on(wtp_ctx* ctx, hipStream_t stream, int n_msgs, const i
                            const int64_t* n_send, void* const* d_recv, const int64_t* n_recv); // wtp_comm.hip
 template <typename T> int launch_radius_dense(wtp_ctx* ctx, SearchArgs<T>& a, T r, int32_t* d_counts); // wtp_radb.hip
 template <typename T> int radius_dense_hcap();
+int launch_cs_ball64(wtp_ctx* ctx, SearchArgs<double>& a, int32_t* rest_list, int32_t* rest_count); // wtp_ball64.hip
 int relax_prerank(wtp_ctx* ctx, int64_t n_fixed_new); // first half of the next rebuild's hash, ahead of wtp_relax_set_fixed_dev (see wtp_api.hip)
 void block_destroy(wtp_ctx* ctx);                                          // frees ctx->block (wtp_destroy)
 template <typename T>
