@@ -362,6 +362,19 @@ def _graded_legs(out, ctx, np, wtp_amd, time, torch):
         "note": "64x density contrast; cell edge measured from the occupancy; points whose support exceeds a cell "
                 "are finished by the ball kernel (wtp_cs2.hip), the rest (exact_path_fraction) by the wave-per-query path; "
                 "the law (1-NN in the boundary kd-tree) is evaluated at every movable point before every sweep"}
+    # the same session in Float64 (the reference's default type): brick_cs_kernel<double>, cs_ball64_kernel for the wide supports
+    wall64 = wall.astype(np.float64)
+    law64 = wtp_amd.BoundaryLayerSpacing(wall64, at_wall=hw, bulk=4 * hw, layer_thickness=0.2)
+    with ctx.relax(np.concatenate([wall64, xg.astype(np.float64)]), len(wall), law64.desc(), dict(kind=2, beta=0.2, u0=1.0, gamma=3.0), 21,
+                   hw / 2000, hw / 20) as t:
+        t.run_async_free(3, 1)
+        t0 = time.perf_counter()
+        _, st = t.run(10, 1)
+        dt = (time.perf_counter() - t0) / 10
+    out["graded_repel_10M_boundary_layer_law_f64"] = {
+        "value": round(ng / dt / 1e6, 1), "unit": "Mpoints/s", "ms_per_iter": round(dt * 1e3, 3),
+        "exact_path_fraction": round(st["n_fallback"] / ng, 5),
+        "note": "Float64 cloud and law; sums in ascending (d2, id) order on every path (bit-identical to the sequential evaluation)"}
     # RadiusTopology on the same cloud (fp32 and fp64), r = 2.5 h_wall
     for name, xx in (("f32", xg), ("f64", xg.astype(np.float64))):
         ctx.radius(xx, 2.5 * hw)  # (full size: the call's scratch — parked rows, 320 B per point — is allocated and touched once)
