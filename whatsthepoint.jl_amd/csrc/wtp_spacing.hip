@@ -254,8 +254,9 @@ __global__ void spacing_session_kernel(const Pt<T>* __restrict__ pts, int64_t n,
                                        const KdNode<T>* __restrict__ nodes, int32_t m, SpacingLaw<T> law,
                                        T* __restrict__ spacing_pp, int32_t* __restrict__ hint,
                                        const int32_t* __restrict__ stop, const int32_t* __restrict__ cell_start,
-                                       const Grid<T>* __restrict__ gp, Pt<T>* __restrict__ cert) {
+                                       const Grid<T>* __restrict__ gp, Pt<T>* __restrict__ cert, int queue_on) {
     __shared__ int32_t kd_stack[kSpThreads / 64][64];
+    __shared__ int32_t kd_queue[kSpThreads / 64][128];
     if (stop && *stop) return;
     // Most walks can be skipped.  A walk leaves, per point, where it stood (x_ref) and a lower bound lb on the distance
     // to every boundary point other than the winner b.  After the point has moved to x, any other boundary point q has
@@ -264,6 +265,29 @@ __global__ void spacing_session_kernel(const Pt<T>* __restrict__ pts, int64_t n,
     // move a fraction of a spacing per sweep and ever less as the cloud relaxes; only the lanes whose certificate
     // fails walk (a wave of fewer interested lanes visits fewer nodes).
     const T eps = sizeof(T) == 4 ? (T)1e-6 : (T)1e-14;
+    int32_t* queue = nullptr; // this wave's queue of slots that must search (128 entries: flushed whenever 64 have gathered)
+    int qn = 0;
+    // the search proper for up to 64 queued (or, without the queue, current) points: packet walk, results, new certificates
+    auto search = [&](int64_t slot, bool need) {
+        const Pt<T> p = pts[need ? slot : 0];
+        const int32_t id = w_to_id(p.w);
+        const int32_t h = need ? hint[id] : -1;
+        int32_t bn;
+        T lb;
+        const T d2 = kd_nearest_d2<T>(nodes, m, p.x, p.y, p.z, need, need ? h : -1, &bn, kd_stack[threadIdx.x >> 6], &lb);
+        if (need) {
+            spacing_pp[id] = spacing_law<T>(law, wsqrt(d2));
+            hint[id] = bn; // points move a fraction of a spacing per sweep: next time this is (nearly) the answer
+            if (cert) {
+                Pt<T> c;
+                c.x = p.x;
+                c.y = p.y;
+                c.z = p.z;
+                c.w = lb;
+                cert[id] = c;
+            }
+        }
+    };
     auto one = [&](int64_t slot, bool on) {
         const Pt<T> p = pts[on ? slot : 0];
         const int32_t id = w_to_id(p.w);
@@ -286,28 +310,31 @@ __global__ void spacing_session_kernel(const Pt<T>* __restrict__ pts, int64_t n,
             }
         }
         if (!__any(need)) return;
-        int32_t bn;
-        T lb;
-        const T d2 = kd_nearest_d2<T>(nodes, m, p.x, p.y, p.z, need, need ? h : -1, &bn, kd_stack[threadIdx.x >> 6], &lb);
-        if (need) {
-            spacing_pp[id] = spacing_law<T>(law, wsqrt(d2));
-            hint[id] = bn; // points move a fraction of a spacing per sweep: next time this is (nearly) the answer
-            if (cert) {
-                Pt<T> c;
-                c.x = p.x;
-                c.y = p.y;
-                c.z = p.z;
-                c.w = lb;
-                cert[id] = c;
+        if (queue) {
+            // The points that must search are queued (their slots) and searched 64 at a time: a tile of 56 points walks as a
+            // whole if ONE of them must, and in a relaxing cloud one usually must (far from a finely sampled wall the two
+            // nearest boundary points are nearly equidistant, so that point's certificate fails whenever it moves).
+            const unsigned long long mk = __ballot(need);
+            const int lane_ = threadIdx.x & 63;
+            if (need) queue[qn + __popcll(mk & ((1ull << lane_) - 1ull))] = (int32_t)slot;
+            qn += __popcll(mk);
+            __builtin_amdgcn_wave_barrier();
+            if (qn >= 64) {
+                qn -= 64;
+                search(queue[qn + lane_], true);
             }
+            return;
         }
+        search(slot, need);
     };
+
     if (!cell_start) { // no grid yet (session setup): slot order
         const int64_t stride = (int64_t)gridDim.x * blockDim.x;
         const int64_t span = (n + 63) / 64 * 64; // whole waves walk the tree together
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < span; i += stride) one(i, i < n);
         return;
     }
+    queue = queue_on ? kd_queue[threadIdx.x >> 6] : nullptr;
     const Grid<T> g = *gp;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // tile = W x H x Hz cells, as cubic as the occupancy allows and ~56 points: up to 64 row segments, one per lane
@@ -356,6 +383,10 @@ __global__ void spacing_session_kernel(const Pt<T>* __restrict__ pts, int64_t n,
         }
         __builtin_amdgcn_wave_barrier();
     }
+    if (queue && qn > 0) { // what is left in the queue (fewer than 64)
+        const int lane_ = threadIdx.x & 63;
+        search(queue[lane_ < qn ? lane_ : 0], lane_ < qn);
+    }
 }
 
 static int sp_grid(int64_t n) {
@@ -380,7 +411,7 @@ int launch_spacing_session(wtp_ctx* ctx, const Pt<T>* pts, int64_t n, int64_t fi
     SpacingLaw<T> law{kind, (T)p0, (T)p1, (T)p2};
     hipLaunchKernelGGL(spacing_session_kernel<T>, dim3(sp_grid(n)), dim3(kSpThreads), 0, ctx->stream, pts, n,
                        (int32_t)first_id, (const KdNode<T>*)d_nodes, (int32_t)m, law, d_spacing_pp, d_hint, ctx->stop_dev,
-                       d_cell_start, (const Grid<T>*)d_grid, (Pt<T>*)d_cert);
+                       d_cell_start, (const Grid<T>*)d_grid, (Pt<T>*)d_cert, getenv("WTP_SP_QUEUE") ? atoi(getenv("WTP_SP_QUEUE")) : 1);
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;
 }
