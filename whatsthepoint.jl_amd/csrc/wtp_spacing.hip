@@ -406,7 +406,10 @@ __global__ void spacing_session_kernel(const Pt<T>* __restrict__ pts, int64_t n,
     const int64_t ntiles = (int64_t)tx_n * ty_n * tz_n;
     const int64_t wave_g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     __shared__ int32_t row_end[kSpThreads / 64][64], row_start[kSpThreads / 64][64];
-    for (int64_t t = wave_g; t < ntiles; t += nwaves) {
+    // a wave takes CONSECUTIVE tiles (neighbours along x): what it queues for one search then lies close together
+    const int64_t per_wave = (ntiles + nwaves - 1) / nwaves;
+    const int64_t t_end = (wave_g + 1) * per_wave < ntiles ? (wave_g + 1) * per_wave : ntiles;
+    for (int64_t t = wave_g * per_wave; t < t_end; ++t) {
         const int tx = (int)(t % tx_n), ty = (int)((t / tx_n) % ty_n), tz = (int)(t / ((int64_t)tx_n * ty_n));
         const int x0 = tx * W, x1 = (x0 + W) < g.n[0] ? (x0 + W) : g.n[0];
         // lane r < nrow: its row segment of the tile
