@@ -393,13 +393,16 @@ __global__ void spacing_session_kernel(const Pt<T>* __restrict__ pts, int64_t n,
     const Grid<T> g = *gp;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // tile = W x H x Hz cells, as cubic as the occupancy allows and ~56 points: up to 64 row segments, one per lane
+    // (points per tile: was one batch of 56; with the queue a tile only orders the certificate checks, and fewer, larger tiles
+    // mean fewer chains of cell-table fetches — 112 … 448 measured within 3 % of each other at 10 M points, 160 kept)
+    constexpr float kSpTilePts = 160.f;
     const float rho0 = (float)g.npts / (float)(g.ncells > 0 ? g.ncells : 1);
     const float rho = rho0 > 0.125f ? rho0 : 0.125f;
     const bool flat = g.n[2] <= 1;
-    int H = (int)(flat ? sqrtf(56.f / rho) : cbrtf(56.f / rho) + 0.5f);
+    int H = (int)(flat ? sqrtf(kSpTilePts / rho) : cbrtf(kSpTilePts / rho) + 0.5f);
     H = H < 1 ? 1 : (H > 8 ? 8 : H);
     const int Hz = flat ? 1 : H;
-    int W = (int)(56.f / (rho * (float)(H * Hz)) + 0.5f);
+    int W = (int)(kSpTilePts / (rho * (float)(H * Hz)) + 0.5f);
     W = W < 1 ? 1 : (W > 32 ? 32 : W);
     const int nrow = H * Hz; // <= 64
     const int tx_n = (g.n[0] + W - 1) / W, ty_n = (g.n[1] + H - 1) / H, tz_n = (g.n[2] + Hz - 1) / Hz;
