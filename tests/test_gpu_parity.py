@@ -147,6 +147,22 @@ def test_relax_multi_iteration_tracks_oracle(ctx, O, wtp):
     assert np.quantile(err, 0.999) < 1e-3
 
 
+def test_relax_stale_snapshot_with_fixed_points_and_larger_cloud(ctx, O, wtp):
+    # rebuild_every = 3 (src/repel.jl:245): two of three sweeps run against a stale snapshot — the default law takes the
+    # ball kernel there (every query, the point where it is now), fixed points and whatever it cannot certify the exact path
+    n, n_fixed = 40000, 4000
+    x = _cloud(wtp, n, 3, np.float32)
+    s, alo, amax = _sweep_args(n)
+    with ctx.relax(x, n_fixed, s, FORCE, 21, alo, amax) as sess:
+        conv, last = sess.run(6, 3)
+        p = sess.positions()
+    ref = O.relax_loop(x, n_fixed, s, 2, 0.2, 1.0, 3.0, 21, alo, amax, max_iters=6, tol=0.0, rebuild_every=3, stall_after=0)
+    assert np.allclose(conv, ref["conv"], rtol=1e-3)
+    err = np.abs(p - ref["p"]).max(axis=1) / s
+    assert np.quantile(err, 0.999) < 1e-3
+    assert last["n_move"] == n - n_fixed
+
+
 def test_relax_stale_snapshot_rebuild_every(ctx, O, wtp):
     n = 8000
     x = _cloud(wtp, n, 3, np.float32)

@@ -1551,7 +1551,8 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
     a.stop = ctx->stop_dev;
     a.nn_list = nullptr;
     a.nn_count = (int32_t*)ctx->fb_count.p + 2;
-    const bool ball = r.cs_sweep && sizeof(T) == 4 && r.spacing_kind != WTP_SPACING_CONSTANT; // wtp_cs2.hip: cs_ball_kernel
+    // wtp_cs2.hip: cs_ball_kernel — variable spacing (supports wider than a cell), and every query of a sweep against a stale snapshot
+    const bool ball = r.cs_sweep && sizeof(T) == 4 && (r.spacing_kind != WTP_SPACING_CONSTANT || r.bufS != r.bufP);
     if (r.cs_sweep && (r.cs2_bx > 0 || ball)) {
         if ((rc = ensure(ctx, ctx->nn_list, sizeof(int32_t) * (size_t)r.n))) return rc;
         a.nn_list = (int32_t*)ctx->nn_list.p;

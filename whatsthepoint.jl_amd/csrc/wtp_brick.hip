@@ -966,7 +966,18 @@ template <> int launch_sweep<float>(wtp_ctx* ctx, SearchArgs<float>& a, bool fre
     ctx->n_sweep_launches += 1;
     if (!fresh || a.k > kFastKMax - 1 || ctx->force_generic) {
         const int sp = span_begin(ctx, 1);
-        int rc = launch_generic_sweep<float>(ctx, a, true);
+        int rc;
+        if (!fresh && !ctx->force_generic && a.ball_list && a.force_kind == WTP_FORCE_CLIPPED_SPACING && a.k >= 2 && !ctx->full_select) {
+            // A stale snapshot (rebuild_every > 1, src/repel.jl:245) and the default law: the query has moved away from its
+            // snapshot entry, so the brick kernels (queries = the staged points) do not apply, but the ball kernel's argument
+            // does — the support ball around the point where it is NOW, searched in the block that provably holds it, at
+            // most k points in it — with eight lanes per query instead of the wave kernel's 64 (10.5 -> see DESIGN.md).
+            rc = launch_cs_all_slots(ctx, a);
+            if (!rc) rc = launch_cs_ball(ctx, a, a.ball_list, a.ball_count);
+            if (!rc) rc = launch_generic_sweep<float>(ctx, a, false);
+        } else {
+            rc = launch_generic_sweep<float>(ctx, a, true);
+        }
         span_end(ctx, sp);
         return rc;
     }

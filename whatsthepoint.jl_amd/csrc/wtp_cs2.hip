@@ -935,7 +935,7 @@ __global__ __launch_bounds__(kBallThreads, 6) void cs_ball_kernel(SearchArgs<flo
         const int i = i0 + grp;
         const bool on = i < n;
         const int gslot = list[on ? i : i0];
-        const float4 qp = a.snap[gslot];
+        const float4 qp = a.query[gslot]; // (the point where it is now: the snapshot's own entry on a fresh one, its moved self on a stale one)
         const int32_t qid = w_to_id(qp.w);
         const float s = a.spacing_pp ? a.spacing_pp[qid] : a.spacing_const;
         const float inv_s2 = 1.f / (s * s);
@@ -1038,6 +1038,18 @@ __global__ __launch_bounds__(kBallThreads, 6) void cs_ball_kernel(SearchArgs<flo
     }
     acc_block_reduce(acc, sacc);
     if (threadIdx.x == 0) acc_store(&a.partials[part_base + blockIdx.x], acc);
+}
+
+// every slot of the snapshot as a hand-back list (sweeps against a stale snapshot: the ball kernel takes all queries)
+__global__ void cs_all_slots_kernel(int32_t* __restrict__ list, int32_t n, int32_t* __restrict__ count) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) list[i] = i;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count = n;
+}
+
+int launch_cs_all_slots(wtp_ctx* ctx, SearchArgs<float>& a) {
+    hipLaunchKernelGGL(cs_all_slots_kernel, dim3(1024), dim3(256), 0, ctx->stream, a.fb_list, a.n, a.fb_count);
+    WTP_HIP(ctx, hipGetLastError());
+    return WTP_OK;
 }
 
 // Runs between the brick kernels' follow-up and the exact path; on return a.fb_list / a.fb_count name what is left.
