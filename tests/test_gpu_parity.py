@@ -163,6 +163,24 @@ def test_relax_stale_snapshot_with_fixed_points_and_larger_cloud(ctx, O, wtp):
     assert last["n_move"] == n - n_fixed
 
 
+def test_relax_stale_snapshot_float64_bit_exact(wtp, O, monkeypatch):
+    # Float64, rebuild_every = 3: the stale sweeps take the Float64 ball kernel (sums in ascending (d2, index) order) —
+    # the same bits as the exact wave path (WTP_BALL64=0) and as the oracle's loop
+    n, n_fixed = 30000, 2000
+    x = _cloud(wtp, n, 3, np.float64)
+    s, alo, amax = _sweep_args(n)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("WTP_BALL64", flag)
+        with wtp.Context(0) as c:
+            with c.relax(x, n_fixed, s, FORCE, 21, alo, amax) as sess:
+                conv, last = sess.run(6, 3)
+                res[flag] = (sess.positions(), np.asarray(conv))
+    assert np.array_equal(res["1"][0], res["0"][0]) and np.array_equal(res["1"][1], res["0"][1])
+    ref = O.relax_loop(x, n_fixed, s, 2, 0.2, 1.0, 3.0, 21, alo, amax, max_iters=6, tol=0.0, rebuild_every=3, stall_after=0)
+    assert np.array_equal(res["1"][0], ref["p"])
+
+
 def test_relax_stale_snapshot_rebuild_every(ctx, O, wtp):
     n = 8000
     x = _cloud(wtp, n, 3, np.float32)

@@ -1561,7 +1561,7 @@ template <typename T> static int relax_step_t(wtp_ctx* ctx, int rebuild, wtp_ste
         a.ball_list = (int32_t*)ctx->nn_list.p;
         a.ball_count = (int32_t*)ctx->fb_count.p + 6;
     }
-    if (r.cs_sweep && sizeof(T) == 8 && r.spacing_kind != WTP_SPACING_CONSTANT && ctx->ball64) { // wtp_ball64.hip: its Float64 twin
+    if (r.cs_sweep && sizeof(T) == 8 && (r.spacing_kind != WTP_SPACING_CONSTANT || r.bufS != r.bufP) && ctx->ball64) { // wtp_ball64.hip: its Float64 twin
         if ((rc = ensure(ctx, ctx->nn_list, sizeof(int32_t) * (size_t)r.n))) return rc;
         a.ball_list = (int32_t*)ctx->nn_list.p;
         a.ball_count = (int32_t*)ctx->fb_count.p + 6;

@@ -972,7 +972,7 @@ template <> int launch_sweep<float>(wtp_ctx* ctx, SearchArgs<float>& a, bool fre
             // snapshot entry, so the brick kernels (queries = the staged points) do not apply, but the ball kernel's argument
             // does — the support ball around the point where it is NOW, searched in the block that provably holds it, at
             // most k points in it — with eight lanes per query instead of the wave kernel's 64 (10.5 -> see DESIGN.md).
-            rc = launch_cs_all_slots(ctx, a);
+            rc = launch_cs_all_slots(ctx, a.fb_list, a.n, a.fb_count);
             if (!rc) rc = launch_cs_ball(ctx, a, a.ball_list, a.ball_count);
             if (!rc) rc = launch_generic_sweep<float>(ctx, a, false);
         } else {
@@ -1032,7 +1032,16 @@ template <> int launch_sweep<double>(wtp_ctx* ctx, SearchArgs<double>& a, bool f
                     a.k <= kFastKMax - 1 && !ctx->full_select && !ctx->force_generic;
     if (!cs) {
         const int sp = span_begin(ctx, 1);
-        int rc = launch_generic_sweep<double>(ctx, a, true);
+        int rc;
+        if (!fresh && a.ball_list && a.force_kind == WTP_FORCE_CLIPPED_SPACING && a.k >= 2 && a.k <= kFastKMax - 1 &&
+            !ctx->full_select && !ctx->force_generic) {
+            // a stale snapshot and the default law: every query through the Float64 ball kernel (as in fp32, launch_sweep<float>)
+            rc = launch_cs_all_slots(ctx, a.fb_list, a.n, a.fb_count);
+            if (!rc) rc = launch_cs_ball64(ctx, a, a.ball_list, a.ball_count);
+            if (!rc) rc = launch_generic_sweep<double>(ctx, a, false);
+        } else {
+            rc = launch_generic_sweep<double>(ctx, a, true);
+        }
         span_end(ctx, sp);
         return rc;
     }

@@ -1046,8 +1046,8 @@ __global__ void cs_all_slots_kernel(int32_t* __restrict__ list, int32_t n, int32
     if (blockIdx.x == 0 && threadIdx.x == 0) *count = n;
 }
 
-int launch_cs_all_slots(wtp_ctx* ctx, SearchArgs<float>& a) {
-    hipLaunchKernelGGL(cs_all_slots_kernel, dim3(1024), dim3(256), 0, ctx->stream, a.fb_list, a.n, a.fb_count);
+int launch_cs_all_slots(wtp_ctx* ctx, int32_t* list, int32_t n, int32_t* count) {
+    hipLaunchKernelGGL(cs_all_slots_kernel, dim3(1024), dim3(256), 0, ctx->stream, list, n, count);
     WTP_HIP(ctx, hipGetLastError());
     return WTP_OK;
 }

@@ -514,7 +514,7 @@ int comm_exchange_peers_on(wtp_ctx* ctx, hipStream_t stream, int n_msgs, const i
                            const int64_t* n_send, void* const* d_recv, const int64_t* n_recv); // wtp_comm.hip
 template <typename T> int launch_radius_dense(wtp_ctx* ctx, SearchArgs<T>& a, T r, int32_t* d_counts); // wtp_radb.hip
 template <typename T> int radius_dense_hcap();
-int launch_cs_all_slots(wtp_ctx* ctx, SearchArgs<float>& a); // wtp_cs2.hip: a.fb_list = 0 .. n-1
+int launch_cs_all_slots(wtp_ctx* ctx, int32_t* list, int32_t n, int32_t* count); // wtp_cs2.hip: list = 0 .. n-1, *count = n
 int launch_cs_ball64(wtp_ctx* ctx, SearchArgs<double>& a, int32_t* rest_list, int32_t* rest_count); // wtp_ball64.hip
 int relax_prerank(wtp_ctx* ctx, int64_t n_fixed_new); // first half of the next rebuild's hash, ahead of wtp_relax_set_fixed_dev (see wtp_api.hip)
 void block_destroy(wtp_ctx* ctx);                                          // frees ctx->block (wtp_destroy)
